@@ -1,0 +1,87 @@
+// Shared declarations for the gfx950 kernels and the C-ABI (include/audiopure.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../include/audiopure.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ap {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define AP_HIP(x)                                  \
+  do {                                             \
+    hipError_t _e = (x);                           \
+    if (_e != hipSuccess) return ap::hip_fail(_e, #x); \
+  } while (0)
+
+constexpr int TT = 128;   // time-tile (samples) of the fused kernels
+constexpr int KC = 16;    // channels per staged K-chunk of the dilated conv (x3 taps = 48 K rows)
+
+// Offsets (in floats) of the reference state-dict tensors inside the weight blob.
+struct BlobLayout {
+  size_t init_b, init_g, init_v;
+  size_t fc1_w, fc1_b, fc2_w, fc2_b;
+  size_t blk0, blk_stride;
+  // inside a block
+  size_t fct_w, fct_b, dil_b, dil_g, dil_v, res_b, res_g, res_v, skip_b, skip_g, skip_v;
+  size_t f1_b, f1_g, f1_v, f2_w, f2_b;
+  size_t total;
+};
+BlobLayout blob_layout(const ap_config &c);
+
+}  // namespace ap
+
+struct ap_ctx {
+  ap_config cfg;
+  int C, S, NL, NW;
+  bool loaded;
+  // schedule (host), reference: util.py:96-123 and diffwave_sde.py:56-60
+  std::vector<float> Beta, Alpha, Alpha_bar, Sigma;
+  std::vector<float> sde_beta, sde_ac;
+  // device weights
+  float *slab;            // one allocation holding everything below
+  size_t slab_elems;
+  float *emb_freq;        // [Ein/2]
+  float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+  float *fct_w, *fct_b;   // [NL][C][Eout], [NL][C]
+  float *w0, *b0;         // folded init conv [C], bias [C]
+  float *w1f;             // [NL][2C][C][3] folded
+  float *w2f;             // [NL][C+S][C] folded (res rows then skip rows)
+  float *wf1f;            // [S][S] folded
+  float *b1;              // [NL][2C]
+  float *b2;              // [NL][C+S]
+  float *bf1, *wf2, *bf2; // [S], [S], [1]
+  float *w1p, *w2p, *wf1p;  // packed fp32 MFMA A-operand images
+  float *norms;           // scratch for row norms
+};
+
+struct ap_m5 {
+  int n_output, n_channel, k1, stride;
+  float *slab;
+  float *w[4], *b[4];
+  float *fcw, *fcb;
+};
+
+// kernel launchers (defined in the .hip files)
+namespace ap {
+int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st);
+int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st);
+int launch_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, hipStream_t st);
+int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
+                    int accumulate, int B, int L, hipStream_t st);
+int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
+                        float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
+                        int B, int L, hipStream_t st);
+int launch_affine_noise(const float *x, float *out, float ca, float cs, const float *z, uint64_t seed,
+                        uint32_t draw, uint64_t utt_offset, int B, int L, hipStream_t st);
+int launch_m5(ap_m5 *m, const float *x, float *logprobs, int B, int L, hipStream_t st);
+int launch_m5_fold(ap_m5 *m, const float *blob, float bn_eps, hipStream_t st);
+}  // namespace ap

@@ -1,0 +1,662 @@
+// gfx950 (MI355X / CDNA4) kernels of the diffusion-purification hot path.
+//
+// Dominant kernel: resblock_f32_kernel — one DiffWave Residual_block.forward
+// (reference: diffusion_models/DiffWave_Unconditional/WaveNet.py:75-97) fused into a single
+// launch: FiLM add, dilated k=3 conv as a [2C x 3C].[3C x Tt] GEMM on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32), tanh*sigmoid gate in registers, res/skip 1x1 convs as a second
+// [(C+S) x C].[C x Tt] GEMM, residual/skip epilogue.  HBM traffic per layer is the algorithmic
+// minimum: read h (+halo), write h', read+write skip.
+#include "ap_common.h"
+
+namespace ap {
+
+__device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// exp(x) on the hardware exp2 with a compensated argument: ~2 ulp over the range the gate uses.
+__device__ __forceinline__ float exp_acc(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
+  const float L2E_LO = 1.92596299e-8f;               // log2 e - L2E_HI
+  float t = x * L2E_HI;
+  float r = __builtin_fmaf(x, L2E_HI, -t);
+  r = __builtin_fmaf(x, L2E_LO, r);
+  float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+
+// tanh(a) * sigmoid(b) = (E - 1) / ((E + 1) (1 + F)),  E = e^{2a}, F = e^{-b}   (WaveNet.py:90)
+__device__ __forceinline__ float gate(float a, float b) {
+  a = fminf(fmaxf(a, -15.0f), 15.0f);    // tanh(+-15) == +-1 in fp32
+  b = fmaxf(b, -80.0f);                  // keep F finite: sigmoid(-80) ~ 1.8e-35
+  float E = exp_acc(2.0f * a);
+  float F = exp_acc(-b);
+  return (E - 1.0f) / ((E + 1.0f) * (1.0f + F));
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight-norm fold (WaveNet.py:23-34; nn.utils.weight_norm dim=0) and MFMA operand packing
+// ---------------------------------------------------------------------------------------------
+__global__ void rownorm_kernel(const float *__restrict__ v, float *__restrict__ norm, int O, int IK) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= O) return;
+  const float *p = v + (size_t)row * IK;
+  float s = 0.f;
+  for (int i = lane; i < IK; i += 64) s = __builtin_fmaf(p[i], p[i], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) norm[row] = sqrtf(s);
+}
+
+// out[o][i] = v[o][i] * (g[o] / ||v[o]||)
+__global__ void fold_kernel(const float *__restrict__ g, const float *__restrict__ v,
+                            const float *__restrict__ norm, float *__restrict__ out, int O, int IK) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)O * IK) return;
+  int o = idx / IK;
+  out[idx] = v[idx] * (g[o] / norm[o]);
+}
+
+// GEMM1 A image: [wave][group][rowtile 4][lane 64][4]; k-step s = 4*group + e; lane (i, h) holds
+// W1[o(wave, rt, i)][kk = 2s + h], kk -> (chunk, tap, c_local) so that the K order matches the
+// staged X rows [tap][c_local] of each 16-channel chunk.  Row tiles interleave tanh / sigmoid halves
+// so a wave owns both pre-activations of its 64 gate channels.
+__global__ void pack_w1_kernel(const float *__restrict__ w1f, float *__restrict__ out, int C) {
+  const int NW = C / 64, NG = C * 3 / 8;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)NW * NG * 4 * 64 * 4;
+  if (idx >= total) return;
+  int e = idx & 3;
+  int lane = (idx >> 2) & 63;
+  int rt = (idx >> 8) & 3;
+  size_t rest = idx >> 10;
+  int G = rest % NG;
+  int w = rest / NG;
+  int s = 4 * G + e, hh = lane >> 5, i = lane & 31;
+  int kk = 2 * s + hh;
+  int chunk = kk / (3 * KC), within = kk % (3 * KC);
+  int tap = within / KC, cl = within % KC;
+  int c = chunk * KC + cl;
+  int o = (rt & 1) * C + 64 * w + 32 * (rt >> 1) + i;
+  out[idx] = w1f[((size_t)o * C + c) * 3 + tap];
+}
+
+// GEMM2 / final-conv A image: [wave][group][rowtile RT][lane][4], rows o = RT*32*wave + 32 rt + i, k = channel.
+__global__ void pack_rows_kernel(const float *__restrict__ wf, float *__restrict__ out, int M, int K, int RT) {
+  const int NG = K / 8;
+  const int NWv = M / (32 * RT);
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)NWv * NG * RT * 64 * 4;
+  if (idx >= total) return;
+  int e = idx & 3;
+  int lane = (idx >> 2) & 63;
+  size_t rest = idx >> 8;
+  int rt = rest % RT;
+  rest /= RT;
+  int G = rest % NG;
+  int w = rest / NG;
+  int s = 4 * G + e, hh = lane >> 5, i = lane & 31;
+  int kk = 2 * s + hh;
+  int o = 32 * RT * w + 32 * rt + i;
+  out[idx] = wf[(size_t)o * K + kk];
+}
+
+__global__ void copy_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = in[idx];
+}
+
+static int fold_one(const float *g, const float *v, float *norms, float *out, int O, int IK, hipStream_t st) {
+  rownorm_kernel<<<(O + 3) / 4, 256, 0, st>>>(v, norms, O, IK);
+  size_t n = (size_t)O * IK;
+  fold_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(g, v, norms, out, O, IK);
+  return 0;
+}
+
+static void copy_to(const float *in, float *out, size_t n, hipStream_t st) {
+  copy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, n);
+}
+
+int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st) {
+  const ap_config &c = ctx->cfg;
+  const int C = ctx->C, S = ctx->S, NL = ctx->NL;
+  BlobLayout bl = blob_layout(c);
+  // init conv (in_channels = 1)
+  fold_one(blob + bl.init_g, blob + bl.init_v, ctx->norms, ctx->w0, C, 1, st);
+  copy_to(blob + bl.init_b, ctx->b0, C, st);
+  copy_to(blob + bl.fc1_w, ctx->fc1_w, (size_t)c.embed_dim_mid * c.embed_dim_in, st);
+  copy_to(blob + bl.fc1_b, ctx->fc1_b, c.embed_dim_mid, st);
+  copy_to(blob + bl.fc2_w, ctx->fc2_w, (size_t)c.embed_dim_out * c.embed_dim_mid, st);
+  copy_to(blob + bl.fc2_b, ctx->fc2_b, c.embed_dim_out, st);
+  for (int n = 0; n < NL; n++) {
+    const float *b = blob + bl.blk0 + (size_t)n * bl.blk_stride;
+    copy_to(b + bl.fct_w, ctx->fct_w + (size_t)n * C * c.embed_dim_out, (size_t)C * c.embed_dim_out, st);
+    copy_to(b + bl.fct_b, ctx->fct_b + (size_t)n * C, C, st);
+    float *w1f = ctx->w1f + (size_t)n * 2 * C * C * 3;
+    float *w2f = ctx->w2f + (size_t)n * (C + S) * C;
+    fold_one(b + bl.dil_g, b + bl.dil_v, ctx->norms, w1f, 2 * C, C * 3, st);
+    fold_one(b + bl.res_g, b + bl.res_v, ctx->norms, w2f, C, C, st);
+    fold_one(b + bl.skip_g, b + bl.skip_v, ctx->norms, w2f + (size_t)C * C, S, C, st);
+    copy_to(b + bl.dil_b, ctx->b1 + (size_t)n * 2 * C, 2 * C, st);
+    copy_to(b + bl.res_b, ctx->b2 + (size_t)n * (C + S), C, st);
+    copy_to(b + bl.skip_b, ctx->b2 + (size_t)n * (C + S) + C, S, st);
+    size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
+    pack_w1_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(w1f, ctx->w1p + (size_t)n * n1, C);
+    pack_rows_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(w2f, ctx->w2p + (size_t)n * n2, C + S, C, 4);
+  }
+  fold_one(blob + bl.f1_g, blob + bl.f1_v, ctx->norms, ctx->wf1f, S, S, st);
+  copy_to(blob + bl.f1_b, ctx->bf1, S, st);
+  copy_to(blob + bl.f2_w, ctx->wf2, S, st);
+  copy_to(blob + bl.f2_b, ctx->bf2, 1, st);
+  size_t nf = (size_t)S * S;
+  pack_rows_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, st>>>(ctx->wf1f, ctx->wf1p, S, S, 2);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// diffusion-step embedding MLP + every block's fc_t   (util.py:68-93; WaveNet.py:82-83,124-126)
+// The step is shared by the whole batch in every caller (diffwave_ddpm.py:157,169,177).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float swish_acc(float x) { return x / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(512) void embed_mlp_kernel(const float *__restrict__ freq, const float *__restrict__ w1,
+                                                        const float *__restrict__ b1, const float *__restrict__ w2,
+                                                        const float *__restrict__ b2, float step, int Ein, int Emid,
+                                                        int Eout, float *__restrict__ emb_out) {
+  extern __shared__ float sm[];
+  float *e0 = sm, *e1 = sm + Ein;
+  int half = Ein / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    float a = step * freq[i];
+    e0[i] = sinf(a);
+    e0[half + i] = cosf(a);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < Emid; o += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < Ein; k++) s = __builtin_fmaf(w1[(size_t)o * Ein + k], e0[k], s);
+    e1[o] = swish_acc(s + b1[o]);
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < Eout; o += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < Emid; k++) s = __builtin_fmaf(w2[(size_t)o * Emid + k], e1[k], s);
+    emb_out[o] = swish_acc(s + b2[o]);
+  }
+}
+
+// part_t[row] = fct_w[row] . emb + fct_b[row]; one wave per row, rows = NL*C
+__global__ void fct_kernel(const float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ emb,
+                           float *__restrict__ out, int rows, int E) {
+  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float *p = w + (size_t)row * E;
+  float s = 0.f;
+  for (int i = lane; i < E; i += 64) s = __builtin_fmaf(p[i], emb[i], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[row] = s + b[row];
+}
+
+int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st) {
+  const ap_config &c = ctx->cfg;
+  // emb vector lives at the tail of part_t's buffer: [NL*C] then [Eout]
+  float *emb = part_t + (size_t)ctx->NL * ctx->C;
+  size_t sm = (size_t)(c.embed_dim_in + c.embed_dim_mid) * sizeof(float);
+  embed_mlp_kernel<<<1, 512, sm, st>>>(ctx->emb_freq, ctx->fc1_w, ctx->fc1_b, ctx->fc2_w, ctx->fc2_b, step,
+                                       c.embed_dim_in, c.embed_dim_mid, c.embed_dim_out, emb);
+  int rows = ctx->NL * ctx->C;
+  fct_kernel<<<(rows + 3) / 4, 256, 0, st>>>(ctx->fct_w, ctx->fct_b, emb, part_t, rows, c.embed_dim_out);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// init conv: h[b][c][t] = max(w0[c] x[b][t] + b0[c], 0)     (WaveNet.py:147,168; ReLU :17-19)
+// ---------------------------------------------------------------------------------------------
+__global__ void init_conv_kernel(const float *__restrict__ x, const float *__restrict__ w0,
+                                 const float *__restrict__ b0, float *__restrict__ h, int C, int L) {
+  int b = blockIdx.z, c = blockIdx.y;
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L) return;
+  float v = __builtin_fmaf(w0[c], x[(size_t)b * L + t], b0[c]);
+  h[((size_t)b * C + c) * L + t] = fmaxf(v, 0.f);
+}
+
+int launch_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, hipStream_t st) {
+  dim3 grid((L + 255) / 256, ctx->C, B);
+  init_conv_kernel<<<grid, 256, 0, st>>>(x, ctx->w0, ctx->b0, h, ctx->C, L);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused residual block, exact fp32 MFMA
+// ---------------------------------------------------------------------------------------------
+template <int C>
+struct RBGeom {
+  static constexpr int NW = C / 64;            // waves per workgroup; wave w owns gate channels [64w, 64w+64)
+  static constexpr int NT = NW * 64;
+  static constexpr int ROWS = 3 * KC;          // staged K rows per chunk (3 taps x 16 channels)
+  static constexpr int NCHUNK = C / KC;
+  static constexpr int GPC = ROWS / 8;         // A groups (4 k-steps of 2) per chunk = 6
+  static constexpr int NG1 = NCHUNK * GPC;     // = 3C/8
+  static constexpr int NG2 = C / 8;
+  static constexpr int EPT = ROWS * TT / NT;   // staged elements per thread per chunk
+  static constexpr int XBUF = ROWS * TT;       // floats per X buffer
+  static constexpr int LDS_FLOATS = (2 * XBUF > C * TT) ? 2 * XBUF : C * TT;
+};
+
+template <int C>
+__global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
+    const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
+    const float *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2p,
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles) {
+  using G = RBGeom<C>;
+  constexpr int NT = G::NT;
+  __shared__ float lds[G::LDS_FLOATS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / ntiles;
+  const int t0 = (blockIdx.x % ntiles) * TT;
+  const float *hin_b = hin + (size_t)b * C * L;
+
+  f32x16 acc[4][4];
+  // accumulators start from the dilated conv's bias
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++) {
+    const int obase = (rt & 1) * C + 64 * wave + 32 * (rt >> 1);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float bv = b1[obase + rowoff(r, hh)];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+    }
+  }
+
+  float xr[G::EPT];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int i = 0; i < G::EPT; i++) {
+      const int e = i * NT + tid;
+      const int row = e >> 7, col = e & 127;
+      const int tap = row / KC, cl = row % KC;
+      const int c = ch * KC + cl;
+      const int tp = t0 + col + (tap - 1) * d;
+      float v = 0.f;
+      if (tp >= 0 && tp < L) v = hin_b[(size_t)c * L + tp] + pt[c];   // u = h + part_t, zero padded (WaveNet.py:84,26-27)
+      xr[i] = v;
+    }
+  };
+  auto store_chunk = [&](float *dst) {
+#pragma unroll
+    for (int i = 0; i < G::EPT; i++) dst[i * NT + tid] = xr[i];
+  };
+
+  load_chunk(0);
+  store_chunk(lds);
+  __syncthreads();
+
+  const f32x4 *ap = reinterpret_cast<const f32x4 *>(w1p) + (size_t)wave * G::NG1 * 4 * 64 + lane;
+  f32x4 a_cur[4], a_nxt[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++) a_cur[rt] = ap[rt * 64];
+
+  for (int ch = 0; ch < G::NCHUNK; ch++) {
+    const float *xb = lds + (ch & 1) * G::XBUF;
+    if (ch + 1 < G::NCHUNK) load_chunk(ch + 1);
+#pragma unroll
+    for (int g = 0; g < G::GPC; g++) {
+      const int Gi = ch * G::GPC + g;
+      if (Gi + 1 < G::NG1) {
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap[(size_t)(Gi + 1) * 256 + rt * 64];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int s = g * 4 + e;
+        float bv[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) bv[ct] = xb[(2 * s + hh) * TT + 32 * ct + j];
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+          for (int ct = 0; ct < 4; ct++)
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rt][e], bv[ct], acc[rt][ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++) a_cur[rt] = a_nxt[rt];
+    }
+    if (ch + 1 < G::NCHUNK) store_chunk(lds + ((ch + 1) & 1) * G::XBUF);
+    __syncthreads();
+  }
+
+  // gated non-linearity (WaveNet.py:90); g -> LDS [C][TT] (aliases the X buffers: all reads retired by the barrier)
+#pragma unroll
+  for (int p = 0; p < 2; p++)
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int c = 64 * wave + 32 * p + rowoff(r, hh);
+        lds[c * TT + 32 * ct + j] = gate(acc[2 * p][ct][r], acc[2 * p + 1][ct][r]);
+      }
+
+  // GEMM2 accumulators: res rows start from b_res + part_t (u = h + part_t re-enters the residual), skip rows from b_skip
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++) {
+    const int obase = 128 * wave + 32 * rt;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int o = obase + rowoff(r, hh);
+      float bv = b2[o];
+      if (obase < C) bv += pt[o];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+    }
+  }
+  __syncthreads();
+
+  const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)wave * G::NG2 * 4 * 64 + lane;
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++) a_cur[rt] = ap2[rt * 64];
+#pragma unroll 2
+  for (int Gi = 0; Gi < G::NG2; Gi++) {
+    if (Gi + 1 < G::NG2) {
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap2[(size_t)(Gi + 1) * 256 + rt * 64];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int s = Gi * 4 + e;
+      float bv[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) bv[ct] = lds[(2 * s + hh) * TT + 32 * ct + j];
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rt][e], bv[ct], acc[rt][ct], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; rt++) a_cur[rt] = a_nxt[rt];
+  }
+
+  // epilogue (WaveNet.py:97, :133)
+  const float RS = 0.707106781186547524f;   // float(math.sqrt(0.5))
+#pragma unroll
+  for (int rt = 0; rt < 4; rt++) {
+    const int obase = 128 * wave + 32 * rt;
+    if (obase < C) {
+      float *ho = hout + (size_t)b * C * L;
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        const int t = t0 + 32 * ct + j;
+        if (t < L) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const size_t off = (size_t)(obase + rowoff(r, hh)) * L + t;
+            ho[off] = (hin_b[off] + acc[rt][ct][r]) * RS;
+          }
+        }
+      }
+    } else {
+      float *sk = skip + (size_t)b * C * L;   // S == C
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        const int t = t0 + 32 * ct + j;
+        if (t < L) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const size_t off = (size_t)(obase - C + rowoff(r, hh)) * L + t;
+            float v = acc[rt][ct][r];
+            if (accumulate) v += sk[off];
+            sk[off] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
+                    int accumulate, int B, int L, hipStream_t st) {
+  const int C = ctx->C, S = ctx->S;
+  const int d = 1 << (layer % ctx->cfg.dilation_cycle);
+  const int ntiles = (L + TT - 1) / TT;
+  const float *w1p = ctx->w1p + (size_t)layer * 2 * C * C * 3;
+  const float *w2p = ctx->w2p + (size_t)layer * (C + S) * C;
+  const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
+  const float *b2 = ctx->b2 + (size_t)layer * (C + S);
+  unsigned grid = (unsigned)B * ntiles;
+  switch (C) {
+    case 64:
+      resblock_f32_kernel<64><<<grid, 64, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      break;
+    case 128:
+      resblock_f32_kernel<128><<<grid, 128, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      break;
+    case 256:
+      resblock_f32_kernel<256><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      break;
+    default:
+      set_error("resblock: unsupported res_channels %d (need 64, 128 or 256)", C);
+      return -22;
+  }
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based noise: Philox4x32-10 + Box-Muller, keyed on (seed; quad, draw, global utterance)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint32_t draw, uint64_t utt, uint32_t quad,
+                                               float (&z)[4]) {
+  uint32_t r[4];
+  philox4x32_10(quad, draw, (uint32_t)utt, (uint32_t)(utt >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const float TWO_PI = 6.283185307179586f;
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    float u1 = ((float)(r[2 * p] >> 9) + 0.5f) * 1.1920928955078125e-07f;      // (0,1), 2^-23
+    float u2 = (float)(r[2 * p + 1] >> 8) * 5.9604644775390625e-08f;           // [0,1), 2^-24
+    float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(TWO_PI * u2, &sn, &cs);
+    z[2 * p] = rad * cs;
+    z[2 * p + 1] = rad * sn;
+  }
+}
+
+__device__ __forceinline__ float philox_normal1(uint64_t seed, uint32_t draw, uint64_t utt, int t) {
+  float z[4];
+  philox_normal4(seed, draw, utt, (uint32_t)t >> 2, z);
+  return z[t & 3];
+}
+
+// out = ca*x + cs*z    (q-sample, diffwave_ddpm.py:66-67)
+__global__ void affine_noise_kernel(const float *__restrict__ x, float *__restrict__ out, float ca, float cs,
+                                    const float *__restrict__ z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
+                                    int L) {
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;   // quad of samples
+  const int t = q * 4;
+  if (t >= L) return;
+  float zz[4];
+  if (z == nullptr) {
+    if (cs != 0.f) philox_normal4(seed, draw, utt_offset + b, (uint32_t)q, zz);
+    else zz[0] = zz[1] = zz[2] = zz[3] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (t + i < L) {
+      const size_t off = (size_t)b * L + t + i;
+      float zv = z ? z[off] : zz[i];
+      float xv = x ? x[off] : 0.f;
+      out[off] = ca * xv + cs * zv;
+    }
+  }
+}
+
+int launch_affine_noise(const float *x, float *out, float ca, float cs, const float *z, uint64_t seed,
+                        uint32_t draw, uint64_t utt_offset, int B, int L, hipStream_t st) {
+  int quads = (L + 3) / 4;
+  dim3 grid((quads + 255) / 256, B);
+  affine_noise_kernel<<<grid, 256, 0, st>>>(x, out, ca, cs, z, seed, draw, utt_offset, L);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// final_conv + clip update:  eps = W_f2 relu(W_f1 (skip * sqrt(1/N)) + b_f1) + b_f2;  out = ca x + cb eps + cs z
+// (WaveNet.py:135,160-162,170; diffwave_ddpm.py:159-160,99-102)
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(S / 64 * 64, 1) void final_f32_kernel(
+    const float *__restrict__ skip, const float *__restrict__ x, float *__restrict__ eps_out, float *__restrict__ out,
+    const float *__restrict__ wf1p, const float *__restrict__ bf1, const float *__restrict__ wf2,
+    const float *__restrict__ bf2, float scale, float ca, float cb, float cs, const float *__restrict__ z,
+    uint64_t seed, uint32_t draw, uint64_t utt_offset, int L, int ntiles) {
+  constexpr int NW = S / 64, NT = NW * 64, NG = S / 8;
+  __shared__ float lds[S * TT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / ntiles;
+  const int t0 = (blockIdx.x % ntiles) * TT;
+  const float *sk = skip + (size_t)b * S * L;
+
+  // stage skip * sqrt(1/N)  ->  lds[S][TT]
+  for (int e = tid; e < S * TT; e += NT) {
+    const int row = e >> 7, col = e & 127;
+    const int t = t0 + col;
+    lds[e] = (t < L) ? sk[(size_t)row * L + t] * scale : 0.f;
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      float bv = bf1[64 * wave + 32 * rt + rowoff(r, hh)];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+    }
+  __syncthreads();
+
+  const f32x4 *ap = reinterpret_cast<const f32x4 *>(wf1p) + (size_t)wave * NG * 2 * 64 + lane;
+  f32x4 a_cur[2], a_nxt[2];
+  a_cur[0] = ap[0];
+  a_cur[1] = ap[64];
+#pragma unroll 2
+  for (int Gi = 0; Gi < NG; Gi++) {
+    if (Gi + 1 < NG) {
+      a_nxt[0] = ap[(size_t)(Gi + 1) * 128];
+      a_nxt[1] = ap[(size_t)(Gi + 1) * 128 + 64];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int s = Gi * 4 + e;
+      float bv[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) bv[ct] = lds[(2 * s + hh) * TT + 32 * ct + j];
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rt][e], bv[ct], acc[rt][ct], 0, 0, 0);
+    }
+    a_cur[0] = a_nxt[0];
+    a_cur[1] = a_nxt[1];
+  }
+  // relu, dot with W_f2 over this wave's 64 rows
+  float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float w = wf2[64 * wave + 32 * rt + rowoff(r, hh)];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) part[ct] = __builtin_fmaf(fmaxf(acc[rt][ct][r], 0.f), w, part[ct]);
+    }
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++) part[ct] += __shfl_xor(part[ct], 32);
+  __syncthreads();   // all MFMA reads of lds retired
+  if (hh == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) lds[wave * TT + 32 * ct + j] = part[ct];
+  }
+  __syncthreads();
+  if (tid < TT) {
+    const int t = t0 + tid;
+    if (t < L) {
+      float e = bf2[0];
+#pragma unroll
+      for (int w = 0; w < NW; w++) e += lds[w * TT + tid];
+      const size_t off = (size_t)b * L + t;
+      if (eps_out) eps_out[off] = e;
+      if (out) {
+        float v = ca * x[off] + cb * e;
+        if (cs != 0.f) {
+          float zv = z ? z[off] : philox_normal1(seed, draw, utt_offset + b, t);
+          v += cs * zv;
+        }
+        out[off] = v;
+      }
+    }
+  }
+}
+
+int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
+                        float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
+                        int B, int L, hipStream_t st) {
+  const int S = ctx->S;
+  const int ntiles = (L + TT - 1) / TT;
+  const float scale = (float)sqrt(1.0 / (double)ctx->NL);   // math.sqrt(1.0/N) (WaveNet.py:135)
+  unsigned grid = (unsigned)B * ntiles;
+#define AP_FINAL(SS)                                                                                             \
+  final_f32_kernel<SS><<<grid, SS, 0, st>>>(skip, x, eps_out, out, ctx->wf1p, ctx->bf1, ctx->wf2, ctx->bf2, scale, \
+                                            ca, cb, cs, z, seed, draw, utt_offset, L, ntiles)
+  switch (S) {
+    case 64: AP_FINAL(64); break;
+    case 128: AP_FINAL(128); break;
+    case 256: AP_FINAL(256); break;
+    default:
+      set_error("final: unsupported skip_channels %d", S);
+      return -22;
+  }
+#undef AP_FINAL
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void philox_fill_kernel(float *__restrict__ out, uint64_t seed, uint32_t draw, uint64_t utt_offset,
+                                   int L) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < L) out[(size_t)b * L + t] = philox_normal1(seed, draw, utt_offset + b, t);
+}
+
+}  // namespace ap
+
+extern "C" int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
+                                void *stream) {
+  dim3 grid((L + 255) / 256, B);
+  ap::philox_fill_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(out, seed, draw, utt_offset, L);
+  AP_HIP(hipGetLastError());
+  return 0;
+}

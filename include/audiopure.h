@@ -1,0 +1,182 @@
+/*
+ * audiopure.h — C-ABI of the MI355X-native diffusion-purification hot path.
+ *
+ * The reference (cychomatica/AudioPure) has no FFI layer: its boundary is Python
+ * class identity.  This header is the boundary a maintainer
+ * would bind from the reference's Python classes (ctypes stub: INTEGRATION.md);
+ * each entry point names the reference code it replaces (file:line relative to
+ * the reference checkout).
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every function returns 0 on success or a
+ *    negative errno-style code and never throws; ap_last_error() gives the text.
+ *  - every `*_dev` / float* tensor argument is a DEVICE pointer owned by the
+ *    caller (e.g. the PyTorch caching allocator); the library allocates device
+ *    memory only inside ap_ctx_create / ap_ctx_load_wavenet / ap_m5_create.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *    All work is enqueued asynchronously on it; nothing synchronises the host
+ *    (ap_ctx_load_wavenet / ap_m5_create excepted), so every launch function is
+ *    hipGraph-capturable.
+ *  - tensors are fp32, layout [B][C][L] row-major with the sample axis contiguous,
+ *    exactly the reference's `[B,1,16000]` / `[B,C,L]` tensors.
+ *  - noise: `z` arguments may be NULL; then N(0,1) samples come from the library's
+ *    counter-based Philox4x32-10 keyed on (seed, draw, GLOBAL utterance index
+ *    = utt_offset + b, sample index), so results do not depend on how a batch
+ *    is sharded over GPUs.  Non-NULL z is used as given (parity tests inject it;
+ *    the reference draws torch.normal on the global RNG, diffwave_ddpm.py:66,100).
+ */
+#ifndef AUDIOPURE_H
+#define AUDIOPURE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ap_ctx ap_ctx;
+typedef struct ap_m5 ap_m5;
+
+/* arithmetic mode of the two residual-block GEMMs */
+enum {
+  AP_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
+  AP_PREC_BF16 = 1   /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM */
+};
+
+/* configs/config.json "wavenet_config" + "diffusion_config" (reference: configs/config.json:2-17) */
+typedef struct ap_config {
+  int32_t res_channels;     /* C  (256) */
+  int32_t skip_channels;    /* S  (256); this build requires S == C, C % 64 == 0, C <= 256 */
+  int32_t num_res_layers;   /* 36 */
+  int32_t dilation_cycle;   /* 12 -> dilation 2^(n mod 12) */
+  int32_t embed_dim_in;     /* 128 */
+  int32_t embed_dim_mid;    /* 512 */
+  int32_t embed_dim_out;    /* 512 */
+  int32_t T;                /* 200 */
+  float beta_0;             /* 1e-4 */
+  float beta_T;             /* 0.02 */
+  int32_t precision;        /* AP_PREC_* */
+} ap_config;
+
+const char *ap_last_error(void);
+int ap_version(void);
+
+/* ---- context -------------------------------------------------------------------------------
+ * replaces: create_diffwave_model (diffusion_models/diffwave_ddpm.py:395-411) +
+ *           calc_diffusion_hyperparams (DiffWave_Unconditional/util.py:96-123).
+ * The schedule tables are computed inside with the reference's sequential fp32 products. */
+int ap_ctx_create(const ap_config *cfg, ap_ctx **out);
+int ap_ctx_destroy(ap_ctx *ctx);
+
+/* Number of fp32 elements of the weight blob for this config. */
+size_t ap_wavenet_blob_elems(const ap_config *cfg);
+
+/* Load the epsilon-network weights.  `blob_dev` is the concatenation (fp32, device) of the
+ * reference checkpoint's `model_state_dict` tensors IN STATE-DICT ORDER, un-folded
+ * (`weight_g`/`weight_v` as stored by nn.utils.weight_norm; WaveNet.py:23-34,138-172):
+ *   init_conv.0.conv.{bias,weight_g,weight_v}, residual_layer.fc_t1.{weight,bias},
+ *   residual_layer.fc_t2.{weight,bias}, then per block n: fc_t.{weight,bias},
+ *   dilated_conv_layer.conv.{bias,weight_g,weight_v}, res_conv.{bias,weight_g,weight_v},
+ *   skip_conv.{bias,weight_g,weight_v}; final_conv.0.conv.{bias,weight_g,weight_v},
+ *   final_conv.2.conv.{weight,bias}.
+ * `embed_freq_dev`: the embed_dim_in/2 frequencies exp(-j ln(1e4)/(half-1)) as the host
+ * computes them (util.py:86-88).  Folds W = g*v/||v|| on device (replaces the 110
+ * _weight_norm_interface calls per forward) and packs the MFMA
+ * operand images.  Synchronises `stream` before returning. */
+int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_elems,
+                        const float *embed_freq_dev, void *stream);
+
+/* Copy the folded (un-packed) weight of one conv back out, for fold-parity tests.
+ * which: 0 = dilated conv of `layer` [2C][C][3], 1 = res_conv [C][C], 2 = skip_conv [S][C],
+ *        3 = final_conv.0 [S][S], 4 = init_conv [C]. */
+int ap_ctx_get_folded(ap_ctx *ctx, int which, int layer, float *out_dev, size_t n_elems, void *stream);
+
+/* Host copies of the schedule (T floats each): which 0=Beta 1=Alpha 2=Alpha_bar 3=Sigma. */
+int ap_ctx_get_schedule(ap_ctx *ctx, int which, float *out_host, int n);
+
+/* Workspace the eps/purify entry points need for a batch of B clips of L samples. */
+size_t ap_workspace_bytes(const ap_ctx *ctx, int B, int L);
+
+/* ---- per-layer / per-step pieces -------------------------------------------------------------
+ * ap_embed: replaces calc_diffusion_step_embedding + fc_t1/fc_t2 swish MLP + every block's fc_t
+ *   (util.py:68-93, WaveNet.py:82-83,124-126).  `step` is the (shared) diffusion step as the
+ *   reference passes it: float(t) (diffwave_ddpm.py:157).  part_t_dev: [num_res_layers][C]. */
+int ap_embed(ap_ctx *ctx, float step, float *part_t_dev, void *stream);
+
+/* ap_init_conv: ReLU(Conv1x1 1->C) (WaveNet.py:147,168).  x [B][1][L] -> h [B][C][L]. */
+int ap_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, void *stream);
+
+/* ap_resblock_fwd: one Residual_block.forward (WaveNet.py:75-97), fused:
+ *   u = h_in + part_t[c]; y = DilConv_{k=3,d}(u) + b; g = tanh(y[:C]) * sigmoid(y[C:]);
+ *   h_out = (u + W_res g + b_res) * sqrt(.5); skip (+)= W_skip g + b_skip.
+ * part_t_layer: [C] for this layer.  accumulate_skip = 0 writes skip (layer 0), else adds.
+ * h_out must not alias h_in (taps at t +- d read other tiles). */
+int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer,
+                    float *h_out, float *skip, int accumulate_skip, int B, int L, void *stream);
+
+/* ap_final_affine: final_conv (WaveNet.py:160-162,170) on skip*sqrt(1/N) (WaveNet.py:135) fused
+ * with an affine update of the clip:  eps = W_f2 ReLU(W_f1 (skip*sqrt(1/N)) + b_f1) + b_f2;
+ *   out = ca * x + cb * eps + cs * z.
+ * eps_out and/or out may be NULL.  z: see header comment (NULL + cs != 0 -> Philox draw `draw`). */
+int ap_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out,
+                    float ca, float cb, float cs, const float *z, uint64_t seed, uint32_t draw,
+                    uint64_t utt_offset, int B, int L, void *stream);
+
+/* out = ca * x + cs * z  (q-sample, diffwave_ddpm.py:66-67; also fills z-only buffers with ca = 0). */
+int ap_affine_noise(const float *x, float *out, float ca, float cs, const float *z, uint64_t seed,
+                    uint32_t draw, uint64_t utt_offset, int B, int L, void *stream);
+
+/* ---- whole network / whole purification -----------------------------------------------------
+ * ap_eps_fwd: WaveNet_Speech_Commands.forward((x, step*ones)) (WaveNet.py:164-172;
+ *   DiffWave.compute_eps_t, diffwave_ddpm.py:166-172).  x, eps_out: [B][1][L]. */
+int ap_eps_fwd(ap_ctx *ctx, const float *x, float step, float *eps_out, int B, int L,
+               void *workspace, size_t ws_bytes, void *stream);
+
+/* ap_purify_ddpm: DiffWave.forward = _diffusion + _reverse (diffwave_ddpm.py:36-104,143-164):
+ *   x <- sqrt(ab[t*-1]) x0 + sqrt(1-ab[t*-1]) z0; for t = t*-1..0: eps = net(x,t);
+ *   mu = (x - (1-a_t)/sqrt(1-ab_t) eps)/sqrt(a_t); x <- mu + Sigma[t] z_t (t>0) | mu.
+ * z_all: NULL (Philox) or t* device tensors [t*][B][L] (z_all[0] = q-sample draw).
+ * do_diffuse = 0 skips the q-sample (DiffWave._reverse alone). */
+int ap_purify_ddpm(ap_ctx *ctx, const float *x0, int t_star, int do_diffuse, const float *z_all,
+                   uint64_t seed, uint64_t utt_offset, float *x_out, int B, int L,
+                   void *workspace, size_t ws_bytes, void *stream);
+
+/* ap_purify_sde: RevDiffWave.audio_editing_sample, sample_step = 1 (diffwave_sde.py:167-212) with
+ * torchsde's fixed-step Euler-Maruyama restated: per k = t*-1..0
+ *   x <- x (1 + b_k/2) - b_k eps(x,k)/sqrt(1-ac_k) + sqrt(b_k) sqrt((1-ac_{k-1})/(1-ac_k)) z  (0 at k=0)
+ * with ac = cumprod(1-b) (diffwave_sde.py:58).  Exactly t* eps-evaluations. */
+int ap_purify_sde(ap_ctx *ctx, const float *x0, int t_star, const float *z_all, uint64_t seed,
+                  uint64_t utt_offset, float *x_out, int B, int L,
+                  void *workspace, size_t ws_bytes, void *stream);
+
+/* ap_one_shot_denoise: DiffWave.one_shot_denoise (diffwave_ddpm.py:174-205), t = t*-1. */
+int ap_one_shot_denoise(ap_ctx *ctx, const float *x_t, int t_star, float *x0_hat, int B, int L,
+                        void *workspace, size_t ws_bytes, void *stream);
+
+/* ---- classifier front-end --------------------------------------------------------------------
+ * ap_m5_*: M5.forward (audio_models/M5/M5Net.py:21-38), BatchNorm in eval mode folded at create.
+ * `blob_dev`: fp32 concat in state-dict order per stage i=1..4:
+ *   conv{i}.weight, conv{i}.bias, bn{i}.weight, bn{i}.bias, bn{i}.running_mean, bn{i}.running_var;
+ *   then fc1.weight, fc1.bias.  x [B][1][L] -> log-probabilities [B][n_output]. */
+int ap_m5_create(int n_output, int n_channel, int first_kernel, int stride, float bn_eps,
+                 const float *blob_dev, size_t n_elems, void *stream, ap_m5 **out);
+int ap_m5_destroy(ap_m5 *m);
+size_t ap_m5_blob_elems(int n_output, int n_channel, int first_kernel);
+int ap_m5_fwd(ap_m5 *m, const float *x, float *logprobs, int B, int L, void *stream);
+
+/* ap_melspec_db: the eval scripts' torchaudio front-end (adaptive_attack_eval.py:83-85):
+ * MelSpectrogram(n_fft=2048, hop=512, n_mels, norm='slaney', mel_scale='slaney', pad_mode='constant')
+ * + AmplitudeToDB('power').  x [B][1][L] -> [B][1][n_mels][1 + L/512].
+ * mode 0: absolute dB (torchaudio); mode 1: librosa power_to_db(ref=max, top_db=80) as
+ * transforms/transforms_stft.py:101-114 (ToSTFT + ToMelSpectrogramFromSTFT). */
+int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L, void *stream);
+
+/* Fill out[B][L] with the library's Philox N(0,1) stream (same values the fused paths use). */
+int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIOPURE_H */

@@ -1,0 +1,319 @@
+"""ORACLE — test infrastructure only.  NOT part of the product path.
+
+CPU restatement (plain fp32 PyTorch CPU ops + numpy; no HIP, no reference
+import) of AudioPure's diffusion-purification hot path.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this file; ``audiopure_amd`` never does.
+
+Pinning: every function below is checked in ``tests/test_oracle_golden.py``
+against golden vectors produced by importing the reference's own modules in
+the build container (``tests/golden/make_golden.py``).
+Two boundaries have no importable reference and no reference test: the
+torchsde 0.2.5 Euler loop (``sde_purify``) and the torchaudio 0.11 mel
+front-end (``melspec_db``) -> **parity unpinned** for the integrator step
+schedule and the mel filterbank; the per-step SDE arithmetic is pinned against
+the reference's ``RevVPSDE.f/g`` (importable with torchsde stubbed).
+
+Citations are ``path:line`` relative to the reference checkout.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# schedule   (diffusion_models/DiffWave_Unconditional/util.py:96-123)
+# --------------------------------------------------------------------------
+def diffusion_hyperparams(T: int, beta_0: float, beta_T: float) -> dict:
+    """Sequential fp32 products exactly as util.py:111-118 (NOT cumprod)."""
+    Beta = torch.linspace(beta_0, beta_T, T)
+    Alpha = 1 - Beta
+    Alpha_bar = Alpha.clone()
+    Beta_tilde = Beta.clone()
+    for t in range(1, T):
+        Alpha_bar[t] = Alpha_bar[t] * Alpha_bar[t - 1]
+        Beta_tilde[t] = Beta_tilde[t] * ((1 - Alpha_bar[t - 1]) / (1 - Alpha_bar[t]))
+    Sigma = torch.sqrt(Beta_tilde)
+    return {"T": T, "Beta": Beta, "Alpha": Alpha, "Alpha_bar": Alpha_bar, "Sigma": Sigma}
+
+
+# --------------------------------------------------------------------------
+# step embedding   (util.py:68-93)
+# --------------------------------------------------------------------------
+def step_embedding(steps: torch.Tensor, dim_in: int = 128) -> torch.Tensor:
+    """steps: float [B,1] -> [B, dim_in] = [sin(t*w_j), cos(t*w_j)], w_j = exp(-j ln(1e4)/(half-1))."""
+    half = dim_in // 2
+    c = np.log(10000) / (half - 1)
+    w = torch.exp(torch.arange(half) * -c)
+    e = steps * w
+    return torch.cat((torch.sin(e), torch.cos(e)), 1)
+
+
+# --------------------------------------------------------------------------
+# weight-norm fold   (WaveNet.py:23-34, nn.utils.weight_norm dim=0)
+# --------------------------------------------------------------------------
+def fold_weight_norm(g: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """W[o] = g[o] * v[o] / ||v[o]||_2, norm over (in, k) per output channel."""
+    n = v.reshape(v.shape[0], -1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+    return v * (g / n)
+
+
+def fold_state_dict(sd: dict) -> dict:
+    """Reference-named state dict -> plain ``.weight``/``.bias`` tensors (fp32 torch)."""
+    out = {}
+    for k, val in sd.items():
+        t = torch.as_tensor(np.asarray(val)) if not isinstance(val, torch.Tensor) else val
+        if k.endswith(".weight_v"):
+            base = k[: -len(".weight_v")]
+            g = sd[base + ".weight_g"]
+            g = torch.as_tensor(np.asarray(g)) if not isinstance(g, torch.Tensor) else g
+            out[base + ".weight"] = fold_weight_norm(g.float(), t.float())
+        elif k.endswith(".weight_g"):
+            continue
+        else:
+            out[k] = t.float() if t.is_floating_point() else t
+    return out
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)  # WaveNet.py:10-11
+
+
+# --------------------------------------------------------------------------
+# epsilon network   (WaveNet.py:53-172)
+# --------------------------------------------------------------------------
+def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor):
+    """One ``Residual_block.forward`` (WaveNet.py:75-97).
+
+    NB the reference's ``h += part_t`` aliases the block input (``h = x`` at :77,
+    in-place add at :84), so the residual branch is ``(x + part_t + res) * sqrt(.5)``.
+    """
+    p = f"residual_layer.residual_blocks.{n}"
+    B, C, L = x.shape
+    part_t = F.linear(emb, w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).view(B, C, 1)    # :82-83
+    u = x + part_t                                                                       # :84 (alias!)
+    h = F.conv1d(u, w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"],
+                 dilation=dilation, padding=dilation)                                    # :87, :26-27
+    out = torch.tanh(h[:, :C, :]) * torch.sigmoid(h[:, C:, :])                           # :90
+    res = F.conv1d(out, w[p + ".res_conv.weight"], w[p + ".res_conv.bias"])              # :93
+    skip = F.conv1d(out, w[p + ".skip_conv.weight"], w[p + ".skip_conv.bias"])           # :95
+    return (u + res) * math.sqrt(0.5), skip                                              # :97
+
+
+def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
+    """``WaveNet_Speech_Commands.forward((audio, diffusion_steps))`` (WaveNet.py:164-172).
+
+    w: folded weights (``fold_state_dict``); x: [B,1,L]; steps: float [B,1].
+    ``taps`` (optional dict) receives per-layer h / running skip for debugging.
+    """
+    N, cyc = cfg["num_res_layers"], cfg["dilation_cycle"]
+    h = F.conv1d(x, w["init_conv.0.conv.weight"], w["init_conv.0.conv.bias"])
+    h = torch.maximum(h, torch.zeros_like(h))                                            # :17-19, :168
+    emb = step_embedding(steps, cfg["diffusion_step_embed_dim_in"])                      # :124
+    emb = _swish(F.linear(emb, w["residual_layer.fc_t1.weight"], w["residual_layer.fc_t1.bias"]))   # :125
+    emb = _swish(F.linear(emb, w["residual_layer.fc_t2.weight"], w["residual_layer.fc_t2.bias"]))   # :126
+    skip = 0
+    for n in range(N):                                                                   # :131-133
+        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb)
+        skip = skip + skip_n
+        if taps is not None:
+            taps[f"h{n}"] = h
+            taps[f"skip{n}"] = skip
+    y = skip * math.sqrt(1.0 / N)                                                        # :135
+    y = F.conv1d(y, w["final_conv.0.conv.weight"], w["final_conv.0.conv.bias"])          # :160
+    y = F.relu(y)                                                                        # :161
+    return F.conv1d(y, w["final_conv.2.conv.weight"], w["final_conv.2.conv.bias"])       # :162
+
+
+def _steps(B: int, t) -> torch.Tensor:
+    return float(t) * torch.ones((B, 1))                                                 # diffwave_ddpm.py:157
+
+
+# --------------------------------------------------------------------------
+# DDPM purification   (diffusion_models/diffwave_ddpm.py:49-104,143-164)
+# --------------------------------------------------------------------------
+def q_sample(dh: dict, x0: torch.Tensor, t_star: int, z: torch.Tensor) -> torch.Tensor:
+    ab = dh["Alpha_bar"][t_star - 1]
+    return torch.sqrt(ab) * x0 + torch.sqrt(1 - ab) * z                                  # :67
+
+
+def ddpm_coefficients(w, cfg, dh, x, t: int):
+    eps = eps_net(w, cfg, x, _steps(x.shape[0], t))                                      # :157-158
+    A, Ab = dh["Alpha"], dh["Alpha_bar"]
+    mu = (x - (1 - A[t]) / torch.sqrt(1 - Ab[t]) * eps) / torch.sqrt(A[t])               # :159
+    return eps, mu, dh["Sigma"][t]                                                       # :160
+
+
+def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list) -> torch.Tensor:
+    """``DiffWave.forward`` with injected noise: noises[0] = q-sample z, noises[k] = k-th reverse draw."""
+    with torch.no_grad():
+        x = q_sample(dh, x0, t_star, noises[0])
+        k = 1
+        for t in range(t_star - 1, -1, -1):                                              # :95
+            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t)
+            if t > 0:
+                x = mu + sigma * noises[k]                                               # :100
+                k += 1
+            else:
+                x = mu                                                                   # :102
+    return x
+
+
+def one_shot_denoise(w, cfg, dh, x_t: torch.Tensor, t_star: int) -> torch.Tensor:
+    """diffwave_ddpm.py:174-205: one eps-eval at t = t*-1, x0_hat = sqrt(1/ab) x - sqrt(1/ab - 1) eps."""
+    with torch.no_grad():
+        t = t_star - 1
+        eps = eps_net(w, cfg, x_t, _steps(x_t.shape[0], t))
+        Ab = dh["Alpha_bar"]
+        return (1 / Ab).sqrt()[t] * x_t - (1 / Ab - 1).sqrt()[t] * eps                   # :197-203
+
+
+def two_shot_denoise(w, cfg, dh, x_t: torch.Tensor, t_star: int) -> torch.Tensor:
+    """diffwave_ddpm.py:184-226."""
+    with torch.no_grad():
+        t = t_star - 1
+        eps = eps_net(w, cfg, x_t, _steps(x_t.shape[0], t))
+        A, Ab, Bt = dh["Alpha"], dh["Alpha_bar"], dh["Beta"]
+        mu = (Ab[t] / A[0]).sqrt()                                                       # :211
+        sigma = (1 - Ab[t] - (Ab[t] / A[0]) * Bt[0] ** 2).sqrt()                         # :212
+        x1 = (x_t - sigma * eps) / mu                                                    # :214
+        _, mu0, _ = ddpm_coefficients(w, cfg, dh, x1, 0)                                 # :220
+        return mu0
+
+
+# --------------------------------------------------------------------------
+# VP-SDE Euler-Maruyama   (diffusion_models/diffwave_sde.py:56-60,73-134,185-204)
+# --------------------------------------------------------------------------
+def sde_tables(T: int = 200, beta_0: float = 0.0001, beta_T: float = 0.02) -> dict:
+    """RevVPSDE tables: beta_min = beta_0*T, beta_max = beta_T*T, divided by N again (:56,:155-158);
+    ``alphas_cumprod`` is ``torch.cumprod`` here (:58), NOT the sequential loop of util.py."""
+    betas = torch.linspace(beta_0 * T / T, beta_T * T / T, T)
+    alphas = 1.0 - betas
+    ac = torch.cumprod(alphas, dim=0)
+    return {"N": T, "discrete_betas": betas, "alphas_cumprod": ac,
+            "sqrt_1m_alphas_cumprod": torch.sqrt(1.0 - ac)}
+
+
+def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int):
+    """Drift f and diffusion g of the REVERSE SDE in torchsde time at discrete index k
+    (= ``RevVPSDE.f`` / ``.g`` with ``disc_steps = k``; :73-134)."""
+    N = tb["N"]
+    beta_t = tb["discrete_betas"][k] * N                                                 # :77
+    drift = -0.5 * beta_t * x                                                            # :79
+    diffusion = torch.sqrt(beta_t)                                                       # :80
+    eps = eps_net(w, cfg, x.view(x.shape[0], 1, -1), _steps(x.shape[0], k)).view(x.shape[0], -1)   # :95-97
+    score = -eps / tb["sqrt_1m_alphas_cumprod"][k]                                       # :99
+    drift = drift - diffusion ** 2 * score                                               # :104
+    if k > 0:
+        scale = torch.sqrt(1 - tb["alphas_cumprod"][k - 1]) / torch.sqrt(1 - tb["alphas_cumprod"][k])   # :110
+    else:
+        scale = 0.0                                                                      # :113
+    return -drift, scale * diffusion                                                     # :125, :114, :134
+
+
+def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list) -> torch.Tensor:
+    """``RevDiffWave.audio_editing_sample`` (sample_step = 1) with torchsde's Euler scheme
+    ``y <- y + f h + g sqrt(h) z`` restated (torchsde 0.2.5, un-vendored: parity unpinned for
+    the loop itself).  h = 1/N; steps k = t*-1 ... 0: exactly t* eps-evaluations (the reference's
+    spurious extra micro-step for t* >= 10 is documented in SURVEY.md A.3 and omitted)."""
+    N = tb["N"]
+    with torch.no_grad():
+        a = (1 - tb["discrete_betas"]).cumprod(dim=0)                                    # :189
+        x = x0 * a[t_star - 1].sqrt() + noises[0] * (1.0 - a[t_star - 1]).sqrt()         # :190
+        y = x.view(x.shape[0], -1)
+        h = 1.0 / N
+        for i, k in enumerate(range(t_star - 1, -1, -1)):
+            f, g = sde_f_g(w, cfg, tb, y, k)
+            y = y + f * h + g * math.sqrt(h) * noises[1 + i].view(y.shape)
+        return y.view(x.shape)
+
+
+# --------------------------------------------------------------------------
+# mel front-end as configured by the eval scripts (adaptive_attack_eval.py:83-85)
+# torchaudio 0.11 documented semantics; SURVEY.md Appendix A.4.  parity unpinned.
+# --------------------------------------------------------------------------
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-30) / min_log_hz) / logstep, mels)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(n_freqs: int = 1025, f_min: float = 0.0, f_max: float = 8000.0, n_mels: int = 32,
+                   sample_rate: int = 16000) -> np.ndarray:
+    """torchaudio.functional.melscale_fbanks(norm='slaney', mel_scale='slaney') -> [n_freqs, n_mels] fp32."""
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(_hz_to_mel_slaney(f_min), _hz_to_mel_slaney(f_max), n_mels + 2)
+    f_pts = _mel_to_hz_slaney(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+    return (fb * enorm[None, :]).astype(np.float32)
+
+
+def melspec_db(x: torch.Tensor, n_fft: int = 2048, hop: int = 512, n_mels: int = 32,
+               ref_max: bool = False, top_db: float | None = None) -> torch.Tensor:
+    """[B,1,L] -> [B,1,n_mels,frames]: MelSpectrogram(n_fft, hop, n_mels, norm='slaney',
+    pad_mode='constant', mel_scale='slaney', power=2, center=True, periodic hann) -> AmplitudeToDB('power').
+    ``ref_max``/``top_db=80`` give the librosa ``power_to_db(ref=np.max)`` of
+    transforms/transforms_stft.py:101-114 (per-utterance max-normalised)."""
+    B = x.shape[0]
+    w = x.reshape(B, -1)
+    win = torch.hann_window(n_fft, periodic=True)
+    spec = torch.stft(w, n_fft, hop_length=hop, win_length=n_fft, window=win, center=True,
+                      pad_mode="constant", normalized=False, onesided=True, return_complex=True)
+    power = spec.real ** 2 + spec.imag ** 2                              # [B, 1025, frames]
+    fb = torch.from_numpy(mel_filterbank(n_fft // 2 + 1, 0.0, 8000.0, n_mels))
+    mel = torch.matmul(power.transpose(1, 2), fb).transpose(1, 2)       # [B, n_mels, frames]
+    db = 10.0 * torch.log10(torch.clamp(mel, min=1e-10))
+    if ref_max:
+        ref = mel.reshape(B, -1).max(dim=1).values.clamp(min=1e-10)
+        db = db - 10.0 * torch.log10(ref).view(B, 1, 1)
+    if top_db is not None:
+        mx = db.reshape(B, -1).max(dim=1).values.view(B, 1, 1)
+        db = torch.maximum(db, mx - top_db)
+    return db.unsqueeze(1)
+
+
+# --------------------------------------------------------------------------
+# M5 classifier   (audio_models/M5/M5Net.py:21-38), BatchNorm in eval mode
+# --------------------------------------------------------------------------
+def m5_forward(sd: dict, x: torch.Tensor, stride: int = 16, eps: float = 1e-5) -> torch.Tensor:
+    t = {k: (torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v) for k, v in sd.items()}
+    with torch.no_grad():
+        h = x
+        for i, s in ((1, stride), (2, 1), (3, 1), (4, 1)):
+            h = F.conv1d(h, t[f"conv{i}.weight"], t[f"conv{i}.bias"], stride=s)
+            h = F.batch_norm(h, t[f"bn{i}.running_mean"], t[f"bn{i}.running_var"], t[f"bn{i}.weight"],
+                             t[f"bn{i}.bias"], training=False, eps=eps)
+            h = F.max_pool1d(F.relu(h), 4)
+        h = F.avg_pool1d(h, h.shape[-1]).view(h.size(0), -1)
+        h = F.linear(h, t["fc1.weight"], t["fc1.bias"])
+        return F.log_softmax(h, dim=1)
+
+
+# --------------------------------------------------------------------------
+# whole path   (acoustic_system.py:29-53 with defense_type='wave', transform=None for M5)
+# --------------------------------------------------------------------------
+def purify_and_classify(w, cfg, dh, m5_sd, x0, t_star: int, noises: list):
+    x = ddpm_purify(w, cfg, dh, x0, t_star, noises)
+    return x, m5_forward(m5_sd, x)
