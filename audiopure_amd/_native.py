@@ -1,0 +1,122 @@
+"""ctypes binding of include/audiopure.h (audiopure_amd/lib/libaudiopure_hip.so).
+
+There is deliberately NO fallback: if the library is missing or a call fails the
+caller gets an exception, never a silently different code path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaudiopure_hip.so")
+
+AP_PREC_F32 = 0
+AP_PREC_BF16 = 1
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class ApConfig(C.Structure):
+    _fields_ = [("res_channels", C.c_int32), ("skip_channels", C.c_int32), ("num_res_layers", C.c_int32),
+                ("dilation_cycle", C.c_int32), ("embed_dim_in", C.c_int32), ("embed_dim_mid", C.c_int32),
+                ("embed_dim_out", C.c_int32), ("T", C.c_int32), ("beta_0", C.c_float), ("beta_T", C.c_float),
+                ("precision", C.c_int32)]
+
+
+class ApStep(C.Structure):
+    _fields_ = [("step", C.c_float), ("ca", C.c_float), ("cb", C.c_float), ("cs", C.c_float), ("draw", C.c_int32)]
+
+
+_vp, _fp, _u64, _u32, _i, _f, _sz = C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/audiopure.h declares
+SIGNATURES = {
+    "ap_last_error": (C.c_char_p, []),
+    "ap_version": (_i, []),
+    "ap_ctx_create": (_i, [C.POINTER(ApConfig), C.POINTER(_vp)]),
+    "ap_ctx_destroy": (_i, [_vp]),
+    "ap_ctx_set_schedule": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _i]),
+    "ap_ctx_set_sde_schedule": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), _i]),
+    "ap_wavenet_blob_elems": (_sz, [C.POINTER(ApConfig)]),
+    "ap_ctx_load_wavenet": (_i, [_vp, _fp, _sz, _fp, _vp]),
+    "ap_ctx_get_folded": (_i, [_vp, _i, _i, _fp, _sz, _vp]),
+    "ap_ctx_get_schedule": (_i, [_vp, _i, C.POINTER(_f), _i]),
+    "ap_profile_enable": (_i, [_vp, _i]),
+    "ap_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ap_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "ap_embed": (_i, [_vp, _f, _fp, _vp]),
+    "ap_init_conv": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
+    "ap_resblock_fwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "ap_final_affine": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),
+    "ap_affine_noise": (_i, [_fp, _fp, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),
+    "ap_eps_fwd": (_i, [_vp, _fp, _f, _fp, _i, _i, _vp, _sz, _vp]),
+    "ap_eps_affine": (_i, [_vp, _fp, _f, _f, _f, _fp, _fp, _i, _i, _vp, _sz, _vp]),
+    "ap_purify_chain": (_i, [_vp, _fp, _f, _f, C.POINTER(ApStep), _i, _fp, _u64, _u64, _fp, _i, _i, _vp, _sz, _vp]),
+    "ap_purify_ddpm": (_i, [_vp, _fp, _i, _i, _fp, _u64, _u64, _fp, _i, _i, _vp, _sz, _vp]),
+    "ap_purify_sde": (_i, [_vp, _fp, _i, _fp, _u64, _u64, _fp, _i, _i, _vp, _sz, _vp]),
+    "ap_one_shot_denoise": (_i, [_vp, _fp, _i, _fp, _i, _i, _vp, _sz, _vp]),
+    "ap_m5_create": (_i, [_i, _i, _i, _i, _f, _fp, _sz, _vp, C.POINTER(_vp)]),
+    "ap_m5_destroy": (_i, [_vp]),
+    "ap_m5_blob_elems": (_sz, [_i, _i, _i]),
+    "ap_m5_fwd": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
+    "ap_melspec_db": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_philox_normal": (_i, [_fp, _u64, _u32, _u64, _i, _i, _vp]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load the HIP library (once) and bind every declared symbol; raise if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). audiopure_amd has no CPU fallback.")
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise NativeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = l
+    return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ap_last_error()
+        raise NativeError(f"{what} failed with code {rc}: {msg.decode(errors='replace') if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a contiguous fp32 CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    import torch
+    assert isinstance(t, torch.Tensor)
+    if not t.is_cuda:
+        raise NativeError("audiopure_amd ops need device (cuda/HIP) tensors; got a CPU tensor and there is no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise NativeError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def farr(values):
+    a = (C.c_float * len(values))(*[float(v) for v in values])
+    return a

@@ -61,6 +61,10 @@ struct ap_ctx {
   float *bf1, *wf2, *bf2; // [S], [S], [1]
   float *w1p, *w2p, *wf1p;  // packed fp32 MFMA A-operand images
   float *norms;           // scratch for row norms
+  // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
+  bool profile;
+  std::vector<hipEvent_t> ev;   // pairs (start, stop), one pair per launch since the last reset
+  size_t ev_used;
 };
 
 struct ap_m5 {

@@ -29,7 +29,7 @@ __device__ __forceinline__ float gate(float a, float b) {
   b = fmaxf(b, -80.0f);                  // keep F finite: sigmoid(-80) ~ 1.8e-35
   float E = exp_acc(2.0f * a);
   float F = exp_acc(-b);
-  return (E - 1.0f) / ((E + 1.0f) * (1.0f + F));
+  return (E - 1.0f) * __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,9 +259,15 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.x / ntiles;
-  const int t0 = (blockIdx.x % ntiles) * TT;
-  const float *hin_b = hin + (size_t)b * C * L;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x / ntiles);
+  const int t0 = __builtin_amdgcn_readfirstlane((blockIdx.x % ntiles) * TT);
+  const float *hin_b;
+  {   // make the per-utterance base provably wave-uniform (buffer descriptor must live in SGPRs)
+    const uint64_t hb = (uint64_t)(hin + (size_t)b * C * L);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
+    hin_b = (const float *)(((uint64_t)hi << 32) | lo);
+  }
 
   f32x16 acc[4][4];
   // accumulators start from the dilated conv's bias
@@ -276,26 +282,53 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
     }
   }
 
+  // ---- staging of X = [tap][c_local][t] chunks through registers: buffer loads with 32-bit offsets issued at
+  // the head of a chunk, FiLM add + zero-pad select + ds_write at its tail (one barrier per chunk).
+  // Element i of a thread sits at LDS index i*NT + tid = (row_i, col_i); (tap, c_local) of row_i are
+  // compile-time up to `rsel`; only the +-d tap shift and the thread's column are runtime.
+  constexpr int NCOL = (NT >= 128) ? 1 : 128 / NT;       // distinct columns per thread
+  constexpr int RPI = (NT >= 128) ? NT / 128 : 1;        // rows advanced per element index
+  constexpr int NPT = KC / RPI;                          // distinct channels per thread per chunk
+  const int rsel = (NT >= 128) ? (tid >> 7) : 0;
+  unsigned voff[3][NCOL];
+  bool tok[3][NCOL];
+#pragma unroll
+  for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+    for (int cc = 0; cc < NCOL; cc++) {
+      const int col = (NT >= 128) ? (tid & 127) : (cc * NT + tid);
+      const int tp = t0 + col + (tap - 1) * d;
+      tok[tap][cc] = (tp >= 0) && (tp < L);
+      voff[tap][cc] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)rsel * (unsigned)L) * 4u;
+    }
+  const __amdgpu_buffer_rsrc_t hrs =
+      __builtin_amdgcn_make_buffer_rsrc((void *)hin_b, 0, (int)((unsigned)C * (unsigned)L * 4u), 0x00020000);
   float xr[G::EPT];
-  auto load_chunk = [&](int ch) {
+  float ptv[NPT];
+  auto issue_loads = [&](int ch) {
+#pragma unroll
+    for (int q = 0; q < NPT; q++) ptv[q] = pt[ch * KC + q * RPI + rsel];
 #pragma unroll
     for (int i = 0; i < G::EPT; i++) {
-      const int e = i * NT + tid;
-      const int row = e >> 7, col = e & 127;
-      const int tap = row / KC, cl = row % KC;
-      const int c = ch * KC + cl;
-      const int tp = t0 + col + (tap - 1) * d;
-      float v = 0.f;
-      if (tp >= 0 && tp < L) v = hin_b[(size_t)c * L + tp] + pt[c];   // u = h + part_t, zero padded (WaveNet.py:84,26-27)
-      xr[i] = v;
+      const int rowc = (NT >= 128) ? i * RPI : i / NCOL;       // compile-time part of the row
+      const int cc = (NT >= 128) ? 0 : i % NCOL;
+      const int tap = rowc / KC, clc = rowc % KC;
+      const int soff = (ch * KC + clc) * L * 4;                // wave-uniform
+      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, voff[tap][cc], soff, 0));
     }
   };
   auto store_chunk = [&](float *dst) {
 #pragma unroll
-    for (int i = 0; i < G::EPT; i++) dst[i * NT + tid] = xr[i];
+    for (int i = 0; i < G::EPT; i++) {
+      const int rowc = (NT >= 128) ? i * RPI : i / NCOL;
+      const int cc = (NT >= 128) ? 0 : i % NCOL;
+      const int tap = rowc / KC, clc = rowc % KC;
+      const float u = xr[i] + ptv[clc / RPI];                  // u = h + part_t (WaveNet.py:84)
+      dst[i * NT + tid] = tok[tap][cc] ? u : 0.f;              // zero padding of the conv input (WaveNet.py:26-27)
+    }
   };
 
-  load_chunk(0);
+  issue_loads(0);
   store_chunk(lds);
   __syncthreads();
 
@@ -304,22 +337,22 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
 #pragma unroll
   for (int rt = 0; rt < 4; rt++) a_cur[rt] = ap[rt * 64];
 
-  for (int ch = 0; ch < G::NCHUNK; ch++) {
-    const float *xb = lds + (ch & 1) * G::XBUF;
-    if (ch + 1 < G::NCHUNK) load_chunk(ch + 1);
+  {
+    int ch = 0, g = 0;
+#pragma unroll 1
+    for (int Gi = 0; Gi < G::NG1; Gi++) {
+      if (g == 0 && ch + 1 < G::NCHUNK) issue_loads(ch + 1);
+      {
+        const int Gn = (Gi + 1 < G::NG1) ? Gi + 1 : Gi;         // last iteration re-reads its own group (unused)
 #pragma unroll
-    for (int g = 0; g < G::GPC; g++) {
-      const int Gi = ch * G::GPC + g;
-      if (Gi + 1 < G::NG1) {
-#pragma unroll
-        for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap[(size_t)(Gi + 1) * 256 + rt * 64];
+        for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap[(size_t)Gn * 256 + rt * 64];
       }
+      const float *xb = lds + (ch & 1) * G::XBUF + (g * 8 + hh) * TT + j;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
-        const int s = g * 4 + e;
         float bv[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) bv[ct] = xb[(2 * s + hh) * TT + 32 * ct + j];
+        for (int ct = 0; ct < 4; ct++) bv[ct] = xb[e * 2 * TT + 32 * ct];
 #pragma unroll
         for (int rt = 0; rt < 4; rt++)
 #pragma unroll
@@ -328,9 +361,13 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
       }
 #pragma unroll
       for (int rt = 0; rt < 4; rt++) a_cur[rt] = a_nxt[rt];
+      if (++g == G::GPC) {
+        if (ch + 1 < G::NCHUNK) store_chunk(lds + ((ch + 1) & 1) * G::XBUF);
+        __syncthreads();
+        g = 0;
+        ch++;
+      }
     }
-    if (ch + 1 < G::NCHUNK) store_chunk(lds + ((ch + 1) & 1) * G::XBUF);
-    __syncthreads();
   }
 
   // gated non-linearity (WaveNet.py:90); g -> LDS [C][TT] (aliases the X buffers: all reads retired by the barrier)
@@ -362,11 +399,12 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
   const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)wave * G::NG2 * 4 * 64 + lane;
 #pragma unroll
   for (int rt = 0; rt < 4; rt++) a_cur[rt] = ap2[rt * 64];
-#pragma unroll 2
+#pragma unroll 1
   for (int Gi = 0; Gi < G::NG2; Gi++) {
-    if (Gi + 1 < G::NG2) {
+    {
+      const int Gn = (Gi + 1 < G::NG2) ? Gi + 1 : Gi;
 #pragma unroll
-      for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap2[(size_t)(Gi + 1) * 256 + rt * 64];
+      for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap2[(size_t)Gn * 256 + rt * 64];
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -384,39 +422,40 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
     for (int rt = 0; rt < 4; rt++) a_cur[rt] = a_nxt[rt];
   }
 
-  // epilogue (WaveNet.py:97, :133)
+  // epilogue (WaveNet.py:97, :133): 32-bit offsets from wave-uniform bases, one (rt, ct) tile at a time
   const float RS = 0.707106781186547524f;   // float(math.sqrt(0.5))
+  float *ho = hout + (size_t)b * C * L;
+  float *sk = skip + (size_t)b * C * L;     // S == C
 #pragma unroll
   for (int rt = 0; rt < 4; rt++) {
     const int obase = 128 * wave + 32 * rt;
-    if (obase < C) {
-      float *ho = hout + (size_t)b * C * L;
+    const bool is_res = obase < C;          // wave-uniform
+    const unsigned rbase = (unsigned)((is_res ? obase : obase - C) + 4 * hh) * (unsigned)L;
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) {
-        const int t = t0 + 32 * ct + j;
-        if (t < L) {
+    for (int ct = 0; ct < 4; ct++) {
+      const int t = t0 + 32 * ct + j;
+      if (t < L) {
+        if (is_res) {
 #pragma unroll
           for (int r = 0; r < 16; r++) {
-            const size_t off = (size_t)(obase + rowoff(r, hh)) * L + t;
+            const unsigned off = rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L + (unsigned)t;
             ho[off] = (hin_b[off] + acc[rt][ct][r]) * RS;
           }
-        }
-      }
-    } else {
-      float *sk = skip + (size_t)b * C * L;   // S == C
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) {
-        const int t = t0 + 32 * ct + j;
-        if (t < L) {
+        } else if (accumulate) {
 #pragma unroll
           for (int r = 0; r < 16; r++) {
-            const size_t off = (size_t)(obase - C + rowoff(r, hh)) * L + t;
-            float v = acc[rt][ct][r];
-            if (accumulate) v += sk[off];
-            sk[off] = v;
+            const unsigned off = rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L + (unsigned)t;
+            sk[off] = sk[off] + acc[rt][ct][r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const unsigned off = rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L + (unsigned)t;
+            sk[off] = acc[rt][ct][r];
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -431,6 +470,20 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
   unsigned grid = (unsigned)B * ntiles;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (ctx->profile) {
+    if (ctx->ev_used + 2 > ctx->ev.size()) {
+      for (int i = 0; i < 2; i++) {
+        hipEvent_t e;
+        AP_HIP(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+      }
+    }
+    ev0 = ctx->ev[ctx->ev_used];
+    ev1 = ctx->ev[ctx->ev_used + 1];
+    ctx->ev_used += 2;
+    AP_HIP(hipEventRecord(ev0, st));
+  }
   switch (C) {
     case 64:
       resblock_f32_kernel<64><<<grid, 64, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
@@ -445,6 +498,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
       set_error("resblock: unsupported res_channels %d (need 64, 128 or 256)", C);
       return -22;
   }
+  if (ev1) AP_HIP(hipEventRecord(ev1, st));
   AP_HIP(hipGetLastError());
   return 0;
 }
@@ -601,12 +655,12 @@ __global__ __launch_bounds__(S / 64 * 64, 1) void final_f32_kernel(
     for (int ct = 0; ct < 4; ct++) lds[wave * TT + 32 * ct + j] = part[ct];
   }
   __syncthreads();
-  if (tid < TT) {
-    const int t = t0 + tid;
+  for (int col = tid; col < TT; col += NT) {
+    const int t = t0 + col;
     if (t < L) {
       float e = bf2[0];
 #pragma unroll
-      for (int w = 0; w < NW; w++) e += lds[w * TT + tid];
+      for (int w = 0; w < NW; w++) e += lds[w * TT + col];
       const size_t off = (size_t)b * L + t;
       if (eps_out) eps_out[off] = e;
       if (out) {

@@ -1,0 +1,121 @@
+// Mel-dB front-end exactly as the eval scripts configure torchaudio (adaptive_attack_eval.py:83-85;
+// SURVEY.md Appendix A.4): center=True zero padding, periodic Hann 2048, hop 512, |rFFT|^2 (1025 bins),
+// slaney mel filterbank with slaney area norm, 10*log10(clamp(., 1e-10)).  One workgroup per (clip, frame):
+// 2048-point Stockham radix-2 FFT entirely in LDS (44 KB), then one thread per mel filter.
+#include <math.h>
+
+#include "ap_common.h"
+
+namespace ap {
+
+constexpr int NFFT = 2048, HOP = 512, NBIN = NFFT / 2 + 1, MAX_MELS = 128;
+
+struct MelPts {
+  float f[MAX_MELS + 2];   // filter corner frequencies in Hz (n_mels + 2 used)
+};
+
+__global__ __launch_bounds__(256) void melspec_kernel(const float *__restrict__ x, float *__restrict__ out, MelPts pts,
+                                                      int n_mels, int n_frames, int L) {
+  __shared__ float2 bufA[NFFT];
+  __shared__ float2 bufB[NFFT];
+  __shared__ float2 tw[NFFT / 2];
+  __shared__ float pw[NBIN];
+  const int tid = threadIdx.x;
+  const int frame = blockIdx.x, b = blockIdx.y;
+  const float *xb = x + (size_t)b * L;
+  for (int m = tid; m < NFFT / 2; m += 256) {
+    float s, c;
+    sincospif((float)m * (1.0f / 1024.0f), &s, &c);   // exp(-2 pi i m / 2048)
+    tw[m] = make_float2(c, -s);
+  }
+  for (int n = tid; n < NFFT; n += 256) {
+    const int t = frame * HOP - NFFT / 2 + n;            // center=True, pad_mode='constant'
+    const float v = (t >= 0 && t < L) ? xb[t] : 0.f;
+    const float w = 0.5f - 0.5f * cospif((float)n * (1.0f / 1024.0f));   // periodic hann: 0.5 - 0.5 cos(2 pi n / N)
+    bufA[n] = make_float2(v * w, 0.f);
+  }
+  __syncthreads();
+  float2 *src = bufA, *dst = bufB;
+#pragma unroll 1
+  for (int Ns = 1; Ns < NFFT; Ns <<= 1) {
+    const int tstride = (NFFT / 2) / Ns;
+    for (int jj = tid; jj < NFFT / 2; jj += 256) {
+      const int k = jj & (Ns - 1);
+      const float2 w = tw[k * tstride];
+      const float2 a = src[jj];
+      const float2 c = src[jj + NFFT / 2];
+      const float2 bw = make_float2(c.x * w.x - c.y * w.y, c.x * w.y + c.y * w.x);
+      const int o = ((jj - k) << 1) + k;
+      dst[o] = make_float2(a.x + bw.x, a.y + bw.y);
+      dst[o + Ns] = make_float2(a.x - bw.x, a.y - bw.y);
+    }
+    __syncthreads();
+    float2 *t = src; src = dst; dst = t;
+  }
+  for (int k = tid; k < NBIN; k += 256) {
+    const float2 v = src[k];
+    pw[k] = v.x * v.x + v.y * v.y;          // power = 2
+  }
+  __syncthreads();
+  if (tid < n_mels) {
+    const float f0 = pts.f[tid], f1 = pts.f[tid + 1], f2 = pts.f[tid + 2];
+    const float binhz = 8000.0f / (float)(NBIN - 1);   // all_freqs = linspace(0, sr/2, n_freqs)
+    int lo = (int)floorf(f0 / binhz), hi = (int)ceilf(f2 / binhz);
+    lo = max(lo, 0);
+    hi = min(hi, NBIN - 1);
+    const float enorm = 2.0f / (f2 - f0);              // slaney area normalisation
+    const float id = 1.0f / (f1 - f0), iu = 1.0f / (f2 - f1);
+    float s = 0.f;
+    for (int k = lo; k <= hi; k++) {
+      const float fr = (float)k * binhz;
+      const float w = fmaxf(0.f, fminf((fr - f0) * id, (f2 - fr) * iu));
+      s = __builtin_fmaf(w * enorm, pw[k], s);
+    }
+    out[((size_t)b * n_mels + tid) * n_frames + frame] = 10.0f * log10f(fmaxf(s, 1e-10f));   // AmplitudeToDB('power')
+  }
+}
+
+// librosa.power_to_db(S, ref=np.max) (top_db = 80) on the dB values of one clip: db - max(db), floored at -80
+// (transforms/transforms_stft.py:111-113).
+__global__ __launch_bounds__(256) void mel_refmax_kernel(float *__restrict__ out, int n) {
+  __shared__ float red[256];
+  float *p = out + (size_t)blockIdx.x * n;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, p[i]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  mx = red[0];
+  for (int i = threadIdx.x; i < n; i += 256) p[i] = fmaxf(p[i] - mx, -80.0f);
+}
+
+static double hz_to_mel_slaney(double f) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz_slaney(double m) {
+  const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+}  // namespace ap
+
+extern "C" int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L, void *stream) {
+  using namespace ap;
+  if (!x || !out || B < 1 || L < 1) { set_error("ap_melspec_db: bad argument"); return -22; }
+  if (n_mels < 1 || n_mels > MAX_MELS) { set_error("ap_melspec_db: n_mels %d outside [1, %d]", n_mels, MAX_MELS); return -22; }
+  if (mode != 0 && mode != 1) { set_error("ap_melspec_db: mode %d", mode); return -22; }
+  MelPts pts;
+  const double m0 = hz_to_mel_slaney(0.0), m1 = hz_to_mel_slaney(8000.0);
+  for (int i = 0; i < n_mels + 2; i++) pts.f[i] = (float)mel_to_hz_slaney(m0 + (m1 - m0) * i / (n_mels + 1));
+  const int n_frames = 1 + L / HOP;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(n_frames, B);
+  melspec_kernel<<<grid, 256, 0, st>>>(x, out, pts, n_mels, n_frames, L);
+  if (mode == 1) mel_refmax_kernel<<<B, 256, 0, st>>>(out, n_mels * n_frames);
+  AP_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,214 @@
+"""``WaveNet_Speech_Commands`` with the reference's constructor, ``forward((audio, steps))`` contract
+and state-dict key names (diffusion_models/DiffWave_Unconditional/WaveNet.py:138-172), executed by
+the gfx950 HIP library through the C-ABI of include/audiopure.h.
+
+The module only *holds* parameters (so ``load_state_dict`` of a reference checkpoint with its
+``weight_g`` / ``weight_v`` entries works unchanged); every FLOP of the forward pass runs in
+``libaudiopure_hip.so``.  There is no PyTorch fallback: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _native as N
+from .util import embedding_frequencies
+
+
+class _WNConv(nn.Module):
+    """Parameter holder named like ``nn.utils.weight_norm(nn.Conv1d)``: bias, weight_g, weight_v."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.weight_g = nn.Parameter(torch.ones(cout, 1, 1))
+        w = torch.empty(cout, cin, k)
+        nn.init.kaiming_normal_(w)
+        self.weight_v = nn.Parameter(w)
+        with torch.no_grad():
+            self.weight_g.copy_(w.reshape(cout, -1).norm(dim=1).view(cout, 1, 1))
+
+
+class _PlainConv(nn.Module):
+    def __init__(self, cin, cout, k, zero=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin, k))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _ConvBox(nn.Module):
+    """Gives the ``.conv`` level of the reference's ``Conv`` / ``ZeroConv1d`` wrappers (WaveNet.py:23-48)."""
+
+    def __init__(self, conv):
+        super().__init__()
+        self.conv = conv
+
+
+class _Linear(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        l = nn.Linear(cin, cout)
+        self.weight = nn.Parameter(l.weight.detach().clone())
+        self.bias = nn.Parameter(l.bias.detach().clone())
+
+
+class _ResidualBlockParams(nn.Module):
+    def __init__(self, C, S, E):
+        super().__init__()
+        self.fc_t = _Linear(E, C)
+        self.dilated_conv_layer = _ConvBox(_WNConv(C, 2 * C, 3))
+        self.res_conv = _WNConv(C, C, 1)
+        self.skip_conv = _WNConv(C, S, 1)
+
+
+class _ResidualGroupParams(nn.Module):
+    def __init__(self, C, S, N, Ein, Emid, Eout):
+        super().__init__()
+        self.fc_t1 = _Linear(Ein, Emid)
+        self.fc_t2 = _Linear(Emid, Eout)
+        self.residual_blocks = nn.ModuleList([_ResidualBlockParams(C, S, Eout) for _ in range(N)])
+
+
+class NativeEngine:
+    """Owns the ap_ctx, the packed weights on the device and a cached workspace."""
+
+    def __init__(self, cfg: dict, precision: int = N.AP_PREC_F32):
+        self.lib = N.lib()
+        self.cfg = N.ApConfig(cfg["res_channels"], cfg["skip_channels"], cfg["num_res_layers"], cfg["dilation_cycle"],
+                              cfg["diffusion_step_embed_dim_in"], cfg["diffusion_step_embed_dim_mid"],
+                              cfg["diffusion_step_embed_dim_out"], 200, 1e-4, 0.02, precision)
+        h = C.c_void_p()
+        N.check(self.lib.ap_ctx_create(C.byref(self.cfg), C.byref(h)), "ap_ctx_create")
+        self.ctx = h
+        self.ws = None
+        self.max_chunk = 512
+        self.loaded_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.ap_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def load(self, blob: torch.Tensor, freq: torch.Tensor):
+        n = self.lib.ap_wavenet_blob_elems(C.byref(self.cfg))
+        if blob.numel() != n:
+            raise N.NativeError(f"weight blob has {blob.numel()} elements, config needs {n}")
+        N.check(self.lib.ap_ctx_load_wavenet(self.ctx, N.ptr(blob), blob.numel(), N.ptr(freq), N.stream()),
+                "ap_ctx_load_wavenet")
+
+    def set_schedule(self, dh: dict):
+        T = int(dh["T"])
+        arrs = [N.farr(dh[k].detach().cpu().float().tolist()) for k in ("Beta", "Alpha", "Alpha_bar", "Sigma")]
+        N.check(self.lib.ap_ctx_set_schedule(self.ctx, arrs[0], arrs[1], arrs[2], arrs[3], T), "ap_ctx_set_schedule")
+
+    def set_sde_schedule(self, betas: torch.Tensor, ac: torch.Tensor):
+        a, b = N.farr(betas.detach().cpu().float().tolist()), N.farr(ac.detach().cpu().float().tolist())
+        N.check(self.lib.ap_ctx_set_sde_schedule(self.ctx, a, b, len(a)), "ap_ctx_set_sde_schedule")
+
+    def workspace(self, B: int, L: int, device) -> torch.Tensor:
+        need = self.lib.ap_workspace_bytes(self.ctx, B, L)
+        if self.ws is None or self.ws.numel() < need or self.ws.device != device:
+            self.ws = None
+            self.ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self.ws
+
+    def chunks(self, B: int):
+        for s in range(0, B, self.max_chunk):
+            yield s, min(B, s + self.max_chunk)
+
+
+class WaveNet_Speech_Commands(nn.Module):
+    def __init__(self, in_channels=1, res_channels=256, skip_channels=128, out_channels=1,
+                 num_res_layers=30, dilation_cycle=10,
+                 diffusion_step_embed_dim_in=128,
+                 diffusion_step_embed_dim_mid=512,
+                 diffusion_step_embed_dim_out=512):
+        super().__init__()
+        if in_channels != 1 or out_channels != 1:
+            raise NotImplementedError("audiopure_amd: only in_channels = out_channels = 1 (raw waveform) is built")
+        self.config = dict(in_channels=in_channels, res_channels=res_channels, skip_channels=skip_channels,
+                           out_channels=out_channels, num_res_layers=num_res_layers, dilation_cycle=dilation_cycle,
+                           diffusion_step_embed_dim_in=diffusion_step_embed_dim_in,
+                           diffusion_step_embed_dim_mid=diffusion_step_embed_dim_mid,
+                           diffusion_step_embed_dim_out=diffusion_step_embed_dim_out)
+        C_, S_ = res_channels, skip_channels
+        # same tree / key names as the reference (WaveNet.py:147-162): init_conv.0.conv.*, residual_layer.*, final_conv.{0,2}.conv.*
+        self.init_conv = nn.Sequential(_ConvBox(_WNConv(in_channels, C_, 1)), nn.Identity())
+        self.residual_layer = _ResidualGroupParams(C_, S_, num_res_layers, diffusion_step_embed_dim_in,
+                                                   diffusion_step_embed_dim_mid, diffusion_step_embed_dim_out)
+        self.final_conv = nn.Sequential(_ConvBox(_WNConv(S_, S_, 1)), nn.Identity(), _ConvBox(_PlainConv(S_, out_channels, 1)))
+        self._engine = None
+        self._precision = N.AP_PREC_F32
+
+    # ---- native plumbing ------------------------------------------------------------------
+    def _blob_tensors(self):
+        r = self.residual_layer
+        ic, f0, f2 = self.init_conv[0].conv, self.final_conv[0].conv, self.final_conv[2].conv
+        ts = [ic.bias, ic.weight_g, ic.weight_v, r.fc_t1.weight, r.fc_t1.bias, r.fc_t2.weight, r.fc_t2.bias]
+        for b in r.residual_blocks:
+            d = b.dilated_conv_layer.conv
+            ts += [b.fc_t.weight, b.fc_t.bias, d.bias, d.weight_g, d.weight_v,
+                   b.res_conv.bias, b.res_conv.weight_g, b.res_conv.weight_v,
+                   b.skip_conv.bias, b.skip_conv.weight_g, b.skip_conv.weight_v]
+        ts += [f0.bias, f0.weight_g, f0.weight_v, f2.weight, f2.bias]
+        return ts
+
+    def engine(self) -> NativeEngine:
+        """Fold + pack the current parameters into the native context (re-done when any parameter changed)."""
+        ts = self._blob_tensors()
+        dev = ts[0].device
+        if dev.type != "cuda":
+            raise N.NativeError("audiopure_amd WaveNet needs its parameters on a HIP device (.cuda()); no CPU path")
+        key = (dev, tuple((t._version, t.data_ptr()) for t in ts))
+        if self._engine is None:
+            self._engine = NativeEngine(self.config, self._precision)
+        if self._engine.loaded_key != key:
+            with torch.no_grad():
+                blob = torch.cat([t.detach().reshape(-1).float() for t in ts]).contiguous()
+                freq = embedding_frequencies(self.config["diffusion_step_embed_dim_in"]).to(dev).contiguous()
+                self._engine.load(blob, freq)
+            self._engine.loaded_key = key
+        return self._engine
+
+    @staticmethod
+    def _check_input(x: torch.Tensor):
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError(
+                "audiopure_amd: gradient through the purifier is not implemented (forward-only HIP path; "
+                "SURVEY.md section 8f).  Call under torch.no_grad() or detach the input.")
+        if x.dim() != 3 or x.shape[1] != 1:
+            raise ValueError(f"expected audio of shape [B,1,L], got {tuple(x.shape)}")
+
+    def eps(self, x: torch.Tensor, step: float) -> torch.Tensor:
+        """eps_theta(x, step) for a step shared by the batch."""
+        self._check_input(x)
+        eng = self.engine()
+        x = x.detach().float().contiguous()
+        B, _, L = x.shape
+        out = torch.empty_like(x)
+        for s, e in eng.chunks(B):
+            ws = eng.workspace(e - s, L, x.device)
+            N.check(eng.lib.ap_eps_fwd(eng.ctx, N.ptr(x[s:e]), float(step), N.ptr(out[s:e]), e - s, L, ws.data_ptr(),
+                                       ws.numel(), N.stream()), "ap_eps_fwd")
+        return out
+
+    def forward(self, input_data):
+        audio, diffusion_steps = input_data          # tuple argument, as the reference (WaveNet.py:164-165)
+        if torch.is_tensor(diffusion_steps):
+            steps = diffusion_steps.detach().reshape(-1).float().cpu()
+            if steps.numel() not in (1, audio.shape[0]):
+                raise ValueError("diffusion_steps must have one entry per clip")
+            uniq = torch.unique(steps)
+            if uniq.numel() == 1:
+                return self.eps(audio, float(uniq[0]))
+            out = torch.empty_like(audio, dtype=torch.float32)
+            for u in uniq.tolist():                    # per-clip steps: one native call per distinct value
+                idx = (steps == u).nonzero().reshape(-1).to(audio.device)
+                out[idx] = self.eps(audio[idx], u)
+            return out
+        return self.eps(audio, float(diffusion_steps))

@@ -1,0 +1,35 @@
+"""Native mel-dB front-ends.
+
+``MelSpecDB`` replaces the eval scripts' ``Compose([torchaudio.transforms.MelSpectrogram(n_fft=2048,
+hop_length=512, n_mels=n_mels, norm='slaney', pad_mode='constant', mel_scale='slaney'),
+AmplitudeToDB(stype='power')])`` (adaptive_attack_eval.py:83-85).
+``ToMelSpectrogramDB`` is the device restatement of the dataset-time ``ToSTFT`` +
+``ToMelSpectrogramFromSTFT`` pair (transforms/transforms_stft.py:14-28,101-114; librosa
+``power_to_db(ref=np.max)``, zero-padded centre frames — SURVEY.md section 8 a12')."""
+import torch
+
+from .. import _native as N
+
+
+class MelSpecDB(torch.nn.Module):
+    mode = 0
+
+    def __init__(self, n_mels: int = 32):
+        super().__init__()
+        self.n_mels = n_mels
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("audiopure_amd MelSpecDB: forward-only HIP path")
+        lead = x.shape[:-1]
+        L = x.shape[-1]
+        xf = x.detach().float().reshape(-1, L).contiguous()
+        B = xf.shape[0]
+        frames = 1 + L // 512
+        out = torch.empty((B, self.n_mels, frames), device=xf.device, dtype=torch.float32)
+        N.check(N.lib().ap_melspec_db(N.ptr(xf), N.ptr(out), self.n_mels, self.mode, B, L, N.stream()), "ap_melspec_db")
+        return out.reshape(*lead, self.n_mels, frames)     # [B,1,L] -> [B,1,n_mels,frames] like torchaudio
+
+
+class ToMelSpectrogramDB(MelSpecDB):
+    mode = 1

@@ -12,7 +12,7 @@
  *    negative errno-style code and never throws; ap_last_error() gives the text.
  *  - every `*_dev` / float* tensor argument is a DEVICE pointer owned by the
  *    caller (e.g. the PyTorch caching allocator); the library allocates device
- *    memory only inside ap_ctx_create / ap_ctx_load_wavenet / ap_m5_create.
+ *    memory only inside ap_ctx_load_wavenet / ap_m5_create.
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
  *    All work is enqueued asynchronously on it; nothing synchronises the host
  *    (ap_ctx_load_wavenet / ap_m5_create excepted), so every launch function is
@@ -65,9 +65,19 @@ int ap_version(void);
 /* ---- context -------------------------------------------------------------------------------
  * replaces: create_diffwave_model (diffusion_models/diffwave_ddpm.py:395-411) +
  *           calc_diffusion_hyperparams (DiffWave_Unconditional/util.py:96-123).
- * The schedule tables are computed inside with the reference's sequential fp32 products. */
+ * Host-only (no device allocation, usable without a GPU).  The default schedule tables are the
+ * closed form evaluated in double and rounded to fp32; a caller that holds the reference's own
+ * fp32 tables (the `diffusion_hyperparams` dict every reference caller passes to DiffWave,
+ * diffwave_ddpm.py:18-32) installs them with ap_ctx_set_schedule so both sides use identical
+ * coefficients. */
 int ap_ctx_create(const ap_config *cfg, ap_ctx **out);
 int ap_ctx_destroy(ap_ctx *ctx);
+
+/* Install T-entry host tables Beta, Alpha, Alpha_bar, Sigma (util.py:111-122). */
+int ap_ctx_set_schedule(ap_ctx *ctx, const float *beta, const float *alpha, const float *alpha_bar,
+                        const float *sigma, int T);
+/* Install the VP-SDE tables discrete_betas, alphas_cumprod (diffwave_sde.py:56-58). */
+int ap_ctx_set_sde_schedule(ap_ctx *ctx, const float *discrete_betas, const float *alphas_cumprod, int T);
 
 /* Number of fp32 elements of the weight blob for this config. */
 size_t ap_wavenet_blob_elems(const ap_config *cfg);
@@ -81,7 +91,7 @@ size_t ap_wavenet_blob_elems(const ap_config *cfg);
  *   skip_conv.{bias,weight_g,weight_v}; final_conv.0.conv.{bias,weight_g,weight_v},
  *   final_conv.2.conv.{weight,bias}.
  * `embed_freq_dev`: the embed_dim_in/2 frequencies exp(-j ln(1e4)/(half-1)) as the host
- * computes them (util.py:86-88).  Folds W = g*v/||v|| on device (replaces the 110
+ * computes them (util.py:86-88).  Allocates the device weight slab, folds W = g*v/||v|| on device (replaces the 110
  * _weight_norm_interface calls per forward) and packs the MFMA
  * operand images.  Synchronises `stream` before returning. */
 int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_elems,
@@ -95,13 +105,20 @@ int ap_ctx_get_folded(ap_ctx *ctx, int which, int layer, float *out_dev, size_t 
 /* Host copies of the schedule (T floats each): which 0=Beta 1=Alpha 2=Alpha_bar 3=Sigma. */
 int ap_ctx_get_schedule(ap_ctx *ctx, int which, float *out_host, int n);
 
+/* Measurement hook (bench.py roofline leg): while enabled, every residual-block launch is bracketed by a
+ * pair of HIP events on the launch stream; ap_profile_read waits for them, returns the summed kernel time
+ * and the number of launches since ap_profile_enable, and resets the counter.  Not graph-capturable while on. */
+int ap_profile_enable(ap_ctx *ctx, int enable);
+int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches);
+
 /* Workspace the eps/purify entry points need for a batch of B clips of L samples. */
 size_t ap_workspace_bytes(const ap_ctx *ctx, int B, int L);
 
 /* ---- per-layer / per-step pieces -------------------------------------------------------------
  * ap_embed: replaces calc_diffusion_step_embedding + fc_t1/fc_t2 swish MLP + every block's fc_t
  *   (util.py:68-93, WaveNet.py:82-83,124-126).  `step` is the (shared) diffusion step as the
- *   reference passes it: float(t) (diffwave_ddpm.py:157).  part_t_dev: [num_res_layers][C]. */
+ *   reference passes it: float(t) (diffwave_ddpm.py:157).  part_t_dev: num_res_layers*C + embed_dim_out
+ *   floats: [num_res_layers][C] FiLM vectors, then the shared 512-d embedding (scratch). */
 int ap_embed(ap_ctx *ctx, float step, float *part_t_dev, void *stream);
 
 /* ap_init_conv: ReLU(Conv1x1 1->C) (WaveNet.py:147,168).  x [B][1][L] -> h [B][C][L]. */
@@ -132,6 +149,26 @@ int ap_affine_noise(const float *x, float *out, float ca, float cs, const float 
  *   DiffWave.compute_eps_t, diffwave_ddpm.py:166-172).  x, eps_out: [B][1][L]. */
 int ap_eps_fwd(ap_ctx *ctx, const float *x, float step, float *eps_out, int B, int L,
                void *workspace, size_t ws_bytes, void *stream);
+
+/* ap_eps_affine: one eps-evaluation that also returns out = ca*x + cb*eps in the same launch sequence
+ * (DiffWave.compute_coefficients -> (eps, mu, sigma), diffwave_ddpm.py:143-164).  eps_out or out may be NULL. */
+int ap_eps_affine(ap_ctx *ctx, const float *x, float step, float ca, float cb, float *eps_out, float *out,
+                  int B, int L, void *workspace, size_t ws_bytes, void *stream);
+
+/* One link of a sampling chain: eps = net(x, step); x <- ca*x + cb*eps + cs*z_draw.
+ * DDPM, the SDE Euler scheme, one-shot denoising and respaced samplers (DiffWave.fast_reverse,
+ * diffwave_ddpm.py:106-141) are all chains of this link with different coefficient tables. */
+typedef struct ap_step {
+  float step;      /* value fed to the step embedding (float(t), diffwave_ddpm.py:157) */
+  float ca, cb, cs;
+  int32_t draw;    /* index into z_all / Philox draw id; ignored when cs == 0 */
+} ap_step;
+
+/* ap_purify_chain: optional q-sample (x <- qa*x0 + qs*z_0; skipped when qa == 1 and qs == 0) followed by
+ * n_steps links.  z_all: NULL (Philox) or [n_draws][B][L] device tensors indexed by `draw`. */
+int ap_purify_chain(ap_ctx *ctx, const float *x0, float qa, float qs, const ap_step *steps, int n_steps,
+                    const float *z_all, uint64_t seed, uint64_t utt_offset, float *x_out, int B, int L,
+                    void *workspace, size_t ws_bytes, void *stream);
 
 /* ap_purify_ddpm: DiffWave.forward = _diffusion + _reverse (diffwave_ddpm.py:36-104,143-164):
  *   x <- sqrt(ab[t*-1]) x0 + sqrt(1-ab[t*-1]) z0; for t = t*-1..0: eps = net(x,t);

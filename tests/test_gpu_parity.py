@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the reference-shaped Python classes) against
+the CPU oracle on the same seeded inputs and against the committed reference-generated golden vectors.
+
+Stated fp32 tolerance: the kernels compute exact fp32 products (v_mfma_f32_32x32x2_f32) with a
+different summation order than oneDNN, so one epsilon-evaluation agrees to ~1e-6 of max|eps|;
+asserted 2e-5 per evaluation and 1e-4 after a 5-step chain (1e-4 * max|x|).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from audiopure_amd import synth
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_EVAL = 2e-5
+TOL_CHAIN = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch.device("cuda:0")
+
+
+def _oracle():
+    from oracle import diffwave_oracle as O
+    return O
+
+
+def _net(cfg, dev, seed=0):
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+    sd = synth.wavenet_state_dict(cfg, seed)
+    net = WaveNet_Speech_Commands(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net.to(dev), sd
+
+
+@pytest.fixture(scope="module")
+def mini(dev):
+    cfg = synth.mini_wavenet_config(64, 12, 12)
+    net, sd = _net(cfg, dev)
+    return cfg, net, _oracle().fold_state_dict(sd)
+
+
+@pytest.fixture(scope="module")
+def full(dev):
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, sd = _net(cfg, dev)
+    return cfg, net, sd
+
+
+@pytest.fixture(scope="module")
+def dh():
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    return calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+
+
+def test_native_library_loaded():
+    from audiopure_amd import _native
+    lib = _native.lib()
+    assert lib.ap_version() >= 100
+
+
+def test_weight_norm_fold_matches_oracle(mini, dev):
+    from audiopure_amd import _native as N
+    cfg, net, w = mini
+    eng = net.engine()
+    Cc = cfg["res_channels"]
+    for which, key, n in ((0, "dilated_conv_layer.conv.weight", 2 * Cc * Cc * 3), (1, "res_conv.weight", Cc * Cc),
+                          (2, "skip_conv.weight", Cc * Cc)):
+        out = torch.empty(n, device=dev)
+        N.check(eng.lib.ap_ctx_get_folded(eng.ctx, which, 5, N.ptr(out), n, N.stream()))
+        ref = w[f"residual_layer.residual_blocks.5.{key}"].reshape(-1)
+        assert rel_err(out.cpu().numpy(), ref.numpy()) < 5e-7
+
+
+@pytest.mark.parametrize("C_,L,layer", [(64, 16000, 0), (64, 16000, 11), (64, 1000, 11), (64, 4133, 6), (64, 130, 3),
+                                        (128, 2500, 9), (256, 1500, 2), (256, 2048, 10)])
+def test_resblock_matches_oracle(dev, C_, L, layer):
+    """One fused Residual_block.forward (WaveNet.py:75-97) vs the oracle, incl. ragged tiles and d >= L."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(C_, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    B = 2
+    h = torch.from_numpy(synth.uniform(f"h/{C_}/{L}", (B, C_, L), 1, -1.5, 1.5))
+    skip0 = torch.from_numpy(synth.uniform(f"s/{C_}/{L}", (B, C_, L), 1, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (B, 512), 1, -1.0, 1.0))
+    emb[1] = emb[0]
+    with torch.no_grad():
+        p = f"residual_layer.residual_blocks.{layer}"
+        part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        h_ref, s_ref = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb)
+    hd, sk = h.to(dev), skip0.to(dev).clone()
+    hout = torch.empty_like(hd)
+    pt = part_t.to(dev).contiguous()
+    N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
+    assert rel_err(hout.cpu().numpy(), h_ref.numpy()) < 5e-6
+    assert rel_err(sk.cpu().numpy(), (skip0 + s_ref).numpy()) < 5e-6
+    sk2 = torch.full_like(sk, 7.0)
+    N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk2), 0, B, L, N.stream()))
+    assert rel_err(sk2.cpu().numpy(), s_ref.numpy()) < 5e-6
+
+
+def test_embed_matches_oracle(mini, dev):
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg, net, w = mini
+    eng = net.engine()
+    NL, Cc = cfg["num_res_layers"], cfg["res_channels"]
+    for step in (0.0, 4.0, 199.0):
+        buf = torch.empty(NL * Cc + 512, device=dev)
+        N.check(eng.lib.ap_embed(eng.ctx, step, N.ptr(buf), N.stream()))
+        with torch.no_grad():
+            e = O.step_embedding(torch.tensor([[step]]), 128)
+            e = O._swish(torch.nn.functional.linear(e, w["residual_layer.fc_t1.weight"], w["residual_layer.fc_t1.bias"]))
+            e = O._swish(torch.nn.functional.linear(e, w["residual_layer.fc_t2.weight"], w["residual_layer.fc_t2.bias"]))
+            ref = torch.cat([torch.nn.functional.linear(e, w[f"residual_layer.residual_blocks.{n}.fc_t.weight"],
+                                                        w[f"residual_layer.residual_blocks.{n}.fc_t.bias"]).reshape(-1)
+                             for n in range(NL)])
+        got = buf[:NL * Cc].cpu()
+        assert (got - ref).abs().max().item() < 2e-5, step
+
+
+@pytest.mark.parametrize("L", [16000, 4133, 1000])
+def test_mini_eps_matches_reference_golden(golden, mini, dev, L):
+    cfg, net, _ = mini
+    x = torch.from_numpy(synth.waveforms(2, L, seed=7)) * 2.0
+    with torch.no_grad():
+        eps = net((x.to(dev), 3.0 * torch.ones(2, 1, device=dev)))
+    assert rel_err(eps.cpu().numpy(), golden[f"mini/L{L}/eps"]) < TOL_EVAL
+
+
+def test_mini_ddpm_chain_matches_reference_golden(golden, mini, dh, dev):
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = mini
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+    dw.set_noise_source([torch.from_numpy(synth.noise(d, 2, 16000, seed=7)) for d in range(3)])
+    x = dw(torch.from_numpy(synth.waveforms(2, 16000, seed=7)).to(dev))
+    assert rel_err(x.cpu().numpy(), golden["mini/ddpm_n3"]) < TOL_CHAIN
+
+
+def test_full_eps_matches_reference_golden(golden, full, dev):
+    cfg, net, _ = full
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
+    with torch.no_grad():
+        eps = net((x0, 4.0 * torch.ones(2, 1, device=dev)))
+    assert rel_err(eps.cpu().numpy(), golden["full/eps_t4"]) < TOL_EVAL
+
+
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_full_ddpm_m5_acoustic_system_match_reference_golden(golden, full, dh, dev, n):
+    """BASELINE config 1 inputs (B=2, L=16000, seed 1234) through AcousticSystem(M5, None, DiffWave)."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.audio_models.M5.M5Net import M5
+    from audiopure_amd.acoustic_system import AcousticSystem
+    cfg, net, _ = full
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=n)
+    m5 = M5(n_input=1, n_output=10)
+    m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
+    m5 = m5.to(dev).eval()
+    assert m5._get_name() == "M5"
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
+    z = [torch.from_numpy(synth.noise(d, 2, 16000, seed=1234)) for d in range(n)]
+    dw.set_noise_source(list(z))
+    xp = dw(x0)
+    assert rel_err(xp.cpu().numpy(), golden[f"full/ddpm_n{n}/x"]) < TOL_CHAIN
+    system = AcousticSystem(classifier=m5, transform=None, defender=dw, defense_type="wave")
+    dw.set_noise_source(list(z))
+    lp = system(x0, True)
+    np.testing.assert_allclose(lp.cpu().numpy(), golden[f"full/ddpm_n{n}/m5_logprobs"], rtol=0, atol=1e-3)
+    lp0 = system(x0, False)
+    np.testing.assert_allclose(lp0.cpu().numpy(), golden["full/acoustic_system_nodefense"], rtol=0, atol=2e-5)
+
+
+def test_full_denoise_helpers_match_reference_golden(golden, full, dh, dev):
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = full
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
+    for t in (1, 25):
+        dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=t)
+        assert rel_err(dw.one_shot_denoise(x0).cpu().numpy(), golden[f"full/one_shot_t{t}"]) < TOL_EVAL
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=25)
+    assert rel_err(dw.two_shot_denoise(x0).cpu().numpy(), golden["full/two_shot_t25"]) < 2 * TOL_EVAL
+    eps, mu, sigma = dw.compute_coefficients(x0, 4)
+    assert rel_err(eps.cpu().numpy(), golden["full/eps_t4"]) < TOL_EVAL
+    a, ab = dh["Alpha"][4], dh["Alpha_bar"][4]
+    mu_ref = (x0.cpu() - (1 - a) / torch.sqrt(1 - ab) * torch.from_numpy(golden["full/eps_t4"])) / torch.sqrt(a)
+    assert rel_err(mu.cpu().numpy(), mu_ref.numpy()) < TOL_EVAL
+    assert float(sigma) == float(dh["Sigma"][4])
+
+
+def test_sde_matches_oracle_and_reference_drift(golden, mini, dh, dev):
+    import types
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    O = _oracle()
+    cfg, net, w = mini
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=4)
+    args = types.SimpleNamespace(t=4, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False,
+                                 sample_step=1, ddpm_path=None, ddpm_config=None)
+    rev = RevDiffWave.from_model(dw, args)
+    # per-step arithmetic pinned to the reference's RevVPSDE.f / .g
+    xs = (torch.from_numpy(synth.waveforms(2, 16000, seed=7)) * 1.5).view(2, -1).to(dev)
+    for k in (0, 4):
+        s = torch.tensor([1.0 - (k + 1.5) / 200.0])
+        assert rel_err(rev.rev_vpsde.f(s, xs).cpu().numpy(), golden[f"mini/sde/f_k{k}"]) < TOL_EVAL
+        np.testing.assert_allclose(rev.rev_vpsde.g(s, xs)[:, :4].cpu().numpy(), golden[f"mini/sde/g_k{k}"], rtol=1e-6)
+    assert np.array_equal(rev.rev_vpsde.discrete_betas.numpy(), golden["mini/sde/discrete_betas"])
+    assert np.array_equal(rev.rev_vpsde.alphas_cumprod.numpy(), golden["mini/sde/alphas_cumprod"])
+    # whole Euler-Maruyama chain vs the oracle restatement
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=7))
+    z = [torch.from_numpy(synth.noise(d, 2, 16000, seed=7)) for d in range(5)]
+    dw.set_noise_source(list(z))
+    got = rev(x0.to(dev))
+    ref = O.sde_purify(w, cfg, O.sde_tables(), x0, 4, z)
+    assert rel_err(got.cpu().numpy(), ref.numpy()) < TOL_CHAIN
+
+
+def test_philox_stream_is_shard_invariant_and_matches_fused_path(mini, dh, dev):
+    """In-kernel Philox == ap_philox_normal fill fed back as explicit z; rows depend only on the global index."""
+    from audiopure_amd import _native as N
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = mini
+    lib = N.lib()
+    B, L, n, seed = 4, 3000, 2, 99
+    x0 = torch.from_numpy(synth.waveforms(B, L, seed=5)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=n)
+    dw.set_noise_source(("philox", seed, 10))
+    full = dw(x0)
+    z = []
+    for d in range(n):
+        t = torch.empty(B, L, device=dev)
+        N.check(lib.ap_philox_normal(N.ptr(t), seed, d, 10, B, L, N.stream()))
+        z.append(t.view(B, 1, L))
+    dw.set_noise_source(z)
+    assert torch.equal(dw(x0), full)
+    dw.set_noise_source(("philox", seed, 12))
+    assert torch.equal(dw(x0[2:]), full[2:])
+    zz = torch.cat([t.reshape(-1) for t in z]).cpu().double()
+    assert abs(zz.mean().item()) < 0.02 and abs(zz.std().item() - 1.0) < 0.02
+
+
+def test_philox_bits_match_numpy_restatement(dev):
+    from audiopure_amd import _native as N
+    from oracle.philox import philox_normal
+    t = torch.empty(3, 1000, device=dev)
+    N.check(N.lib().ap_philox_normal(N.ptr(t), 0x1234567890ABCDEF, 3, (1 << 33) + 5, 3, 1000, N.stream()))
+    ref = philox_normal(0x1234567890ABCDEF, 3, (1 << 33) + 5, 3, 1000)
+    np.testing.assert_allclose(t.cpu().numpy(), ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("L", [16000, 8000, 700])
+def test_m5_matches_oracle(dev, L):
+    from audiopure_amd.audio_models.M5.M5Net import M5
+    O = _oracle()
+    sd = synth.m5_state_dict(35, seed=2)
+    m5 = M5(n_input=1, n_output=35)
+    m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m5 = m5.to(dev).eval()
+    x = torch.from_numpy(synth.waveforms(5, L, seed=8))
+    if L < 1500:
+        with pytest.raises(Exception):
+            m5(x.to(dev))
+        return
+    np.testing.assert_allclose(m5(x.to(dev)).cpu().numpy(), O.m5_forward(sd, x).numpy(), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_melspec_matches_oracle(dev, mode):
+    from audiopure_amd.transforms import MelSpecDB, ToMelSpectrogramDB
+    O = _oracle()
+    x = torch.from_numpy(synth.waveforms(3, 16000, seed=5))
+    tr = (MelSpecDB if mode == 0 else ToMelSpectrogramDB)(32)
+    got = tr(x.to(dev)).cpu()
+    ref = O.melspec_db(x, ref_max=bool(mode), top_db=80.0 if mode else None)
+    assert got.shape == (3, 1, 32, 32)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=5e-3)
+
+
+def test_errors_are_loud(mini, dh, dev):
+    from audiopure_amd import _native as N
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = mini
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    x = torch.from_numpy(synth.waveforms(1, 1000, seed=1)).to(dev)
+    xg = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        with pytest.raises(NotImplementedError):
+            net.eps(xg, 1.0)
+    with pytest.raises(AssertionError):
+        dw(x[0])
+    with pytest.raises(TypeError):
+        DiffWave(model=torch.nn.Linear(2, 2), diffusion_hyperparams=dh)
+    eng = net.engine()
+    with pytest.raises(N.NativeError):
+        N.check(eng.lib.ap_eps_fwd(eng.ctx, N.ptr(x), 0.0, N.ptr(x), 1, 1000, None, 0, N.stream()), "ap_eps_fwd")
+    # numpy input is accepted like the reference (diffwave_ddpm.py:38-39)
+    out = dw(x.cpu().numpy())
+    assert out.shape == x.shape and out.is_cuda
