@@ -234,20 +234,26 @@ int launch_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, hipStr
 // ---------------------------------------------------------------------------------------------
 template <int C>
 struct RBGeom {
-  static constexpr int NW = C / 64;            // waves per workgroup; wave w owns gate channels [64w, 64w+64)
-  static constexpr int NT = NW * 64;
+  static constexpr int NWM = C / 64;           // wave rows: wave (mw, nw) owns gate channels [64mw, 64mw+64) ...
+  static constexpr int NWN = 2;                // ... and time columns [64nw, 64nw+64) of the 128-sample tile
+  static constexpr int NW = NWM * NWN;
+  static constexpr int NT = NW * 64;           // 512 threads at C = 256: two waves per SIMD
   static constexpr int ROWS = 3 * KC;          // staged K rows per chunk (3 taps x 16 channels)
   static constexpr int NCHUNK = C / KC;
   static constexpr int GPC = ROWS / 8;         // A groups (4 k-steps of 2) per chunk = 6
   static constexpr int NG1 = NCHUNK * GPC;     // = 3C/8
   static constexpr int NG2 = C / 8;
-  static constexpr int EPT = ROWS * TT / NT;   // staged elements per thread per chunk
+  static constexpr int EPT = ROWS * TT / NT;   // staged elements per thread per chunk (12 at C = 256)
+  static constexpr int RPI = NT / 128;         // rows advanced per element index
+  static constexpr int NPT = KC / RPI;         // distinct channels per thread per chunk
   static constexpr int XBUF = ROWS * TT;       // floats per X buffer
   static constexpr int LDS_FLOATS = (2 * XBUF > C * TT) ? 2 * XBUF : C * TT;
 };
 
+// One workgroup = one (utterance, 128-sample tile).  Per wave: 128 GEMM rows x 64 columns = 8 accumulator tiles of
+// 32x32 (128 AGPRs), so two waves share each SIMD and one wave's waits/VALU phases overlap the other's MFMAs.
 template <int C>
-__global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
+__global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2p,
     const float *__restrict__ b2, int L, int d, int accumulate, int ntiles) {
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mw = wave >> 1, nw = wave & 1;
   const int j = lane & 31, hh = lane >> 5;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x / ntiles);
   const int t0 = __builtin_amdgcn_readfirstlane((blockIdx.x % ntiles) * TT);
@@ -269,38 +276,32 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
     hin_b = (const float *)(((uint64_t)hi << 32) | lo);
   }
 
-  f32x16 acc[4][4];
-  // accumulators start from the dilated conv's bias
+  f32x16 acc[4][2];
+  // accumulators start from the dilated conv's bias; row tiles interleave tanh (even rt) / sigmoid (odd rt) halves
 #pragma unroll
   for (int rt = 0; rt < 4; rt++) {
-    const int obase = (rt & 1) * C + 64 * wave + 32 * (rt >> 1);
+    const int obase = (rt & 1) * C + 64 * mw + 32 * (rt >> 1);
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       float bv = b1[obase + rowoff(r, hh)];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+      for (int ct = 0; ct < 2; ct++) acc[rt][ct][r] = bv;
     }
   }
 
   // ---- staging of X = [tap][c_local][t] chunks through registers: buffer loads with 32-bit offsets issued at
   // the head of a chunk, FiLM add + zero-pad select + ds_write at its tail (one barrier per chunk).
-  // Element i of a thread sits at LDS index i*NT + tid = (row_i, col_i); (tap, c_local) of row_i are
-  // compile-time up to `rsel`; only the +-d tap shift and the thread's column are runtime.
-  constexpr int NCOL = (NT >= 128) ? 1 : 128 / NT;       // distinct columns per thread
-  constexpr int RPI = (NT >= 128) ? NT / 128 : 1;        // rows advanced per element index
-  constexpr int NPT = KC / RPI;                          // distinct channels per thread per chunk
-  const int rsel = (NT >= 128) ? (tid >> 7) : 0;
-  unsigned voff[3][NCOL];
-  bool tok[3][NCOL];
+  // Element i of a thread sits at LDS index i*NT + tid = (row i*RPI + rsel, col tid & 127).
+  constexpr int RPI = G::RPI, NPT = G::NPT;
+  const int rsel = tid >> 7;
+  unsigned voff[3];
+  bool tok[3];
 #pragma unroll
-  for (int tap = 0; tap < 3; tap++)
-#pragma unroll
-    for (int cc = 0; cc < NCOL; cc++) {
-      const int col = (NT >= 128) ? (tid & 127) : (cc * NT + tid);
-      const int tp = t0 + col + (tap - 1) * d;
-      tok[tap][cc] = (tp >= 0) && (tp < L);
-      voff[tap][cc] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)rsel * (unsigned)L) * 4u;
-    }
+  for (int tap = 0; tap < 3; tap++) {
+    const int tp = t0 + (tid & 127) + (tap - 1) * d;
+    tok[tap] = (tp >= 0) && (tp < L);
+    voff[tap] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)rsel * (unsigned)L) * 4u;
+  }
   const __amdgpu_buffer_rsrc_t hrs =
       __builtin_amdgcn_make_buffer_rsrc((void *)hin_b, 0, (int)((unsigned)C * (unsigned)L * 4u), 0x00020000);
   float xr[G::EPT];
@@ -310,21 +311,19 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
     for (int q = 0; q < NPT; q++) ptv[q] = pt[ch * KC + q * RPI + rsel];
 #pragma unroll
     for (int i = 0; i < G::EPT; i++) {
-      const int rowc = (NT >= 128) ? i * RPI : i / NCOL;       // compile-time part of the row
-      const int cc = (NT >= 128) ? 0 : i % NCOL;
+      const int rowc = i * RPI;                                // compile-time part of the row
       const int tap = rowc / KC, clc = rowc % KC;
       const int soff = (ch * KC + clc) * L * 4;                // wave-uniform
-      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, voff[tap][cc], soff, 0));
+      xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, voff[tap], soff, 0));
     }
   };
   auto store_chunk = [&](float *dst) {
 #pragma unroll
     for (int i = 0; i < G::EPT; i++) {
-      const int rowc = (NT >= 128) ? i * RPI : i / NCOL;
-      const int cc = (NT >= 128) ? 0 : i % NCOL;
+      const int rowc = i * RPI;
       const int tap = rowc / KC, clc = rowc % KC;
       const float u = xr[i] + ptv[clc / RPI];                  // u = h + part_t (WaveNet.py:84)
-      dst[i * NT + tid] = tok[tap][cc] ? u : 0.f;              // zero padding of the conv input (WaveNet.py:26-27)
+      dst[i * NT + tid] = tok[tap] ? u : 0.f;                  // zero padding of the conv input (WaveNet.py:26-27)
     }
   };
 
@@ -332,36 +331,48 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
   store_chunk(lds);
   __syncthreads();
 
-  const f32x4 *ap = reinterpret_cast<const f32x4 *>(w1p) + (size_t)wave * G::NG1 * 4 * 64 + lane;
-  f32x4 a_cur[4], a_nxt[4];
+  // A operands (weights) stream straight from L2 into registers, one group (4 k-steps x 4 row tiles = 16 VGPRs)
+  // ahead of its use, ping-ponging between two named register sets so no copy or early wait is needed.
+  auto load_a = [&](f32x4(&a)[4], const f32x4 *base, int Gi) {
 #pragma unroll
-  for (int rt = 0; rt < 4; rt++) a_cur[rt] = ap[rt * 64];
+    for (int rt = 0; rt < 4; rt++) a[rt] = base[(size_t)Gi * 256 + rt * 64];
+  };
+  auto mma4 = [&](const f32x4(&a)[4], const float *xb) {      // 4 k-steps: 8 LDS reads, 32 MFMAs
+    float bv[4][2];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) bv[e][ct] = xb[e * 2 * TT + 32 * ct];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rt][e], bv[e][ct], acc[rt][ct], 0, 0, 0);
+  };
 
+  const int colbase = 64 * nw + j;
+  const f32x4 *ap = reinterpret_cast<const f32x4 *>(w1p) + (size_t)mw * G::NG1 * 4 * 64 + lane;
+  f32x4 a0[4], a1[4];
+  load_a(a0, ap, 0);
   {
+    static_assert(G::GPC % 2 == 0 && G::NG1 % 2 == 0, "pair-unrolled loop");
     int ch = 0, g = 0;
 #pragma unroll 1
-    for (int Gi = 0; Gi < G::NG1; Gi++) {
+    for (int Gi = 0; Gi < G::NG1; Gi += 2) {
       if (g == 0 && ch + 1 < G::NCHUNK) issue_loads(ch + 1);
-      {
-        const int Gn = (Gi + 1 < G::NG1) ? Gi + 1 : Gi;         // last iteration re-reads its own group (unused)
-#pragma unroll
-        for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap[(size_t)Gn * 256 + rt * 64];
-      }
-      const float *xb = lds + (ch & 1) * G::XBUF + (g * 8 + hh) * TT + j;
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float bv[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++) bv[ct] = xb[e * 2 * TT + 32 * ct];
-#pragma unroll
-        for (int rt = 0; rt < 4; rt++)
-#pragma unroll
-          for (int ct = 0; ct < 4; ct++)
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rt][e], bv[ct], acc[rt][ct], 0, 0, 0);
-      }
-#pragma unroll
-      for (int rt = 0; rt < 4; rt++) a_cur[rt] = a_nxt[rt];
-      if (++g == G::GPC) {
+      load_a(a1, ap, Gi + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float *xb = lds + (ch & 1) * G::XBUF + (g * 8 + hh) * TT + colbase;
+      mma4(a0, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(a0, ap, (Gi + 2 < G::NG1) ? Gi + 2 : Gi);          // last pair re-reads its own group (unused)
+      __builtin_amdgcn_sched_barrier(0);
+      mma4(a1, xb + 8 * TT);
+      __builtin_amdgcn_sched_barrier(0);
+      g += 2;
+      if (g == G::GPC) {
         if (ch + 1 < G::NCHUNK) store_chunk(lds + ((ch + 1) & 1) * G::XBUF);
         __syncthreads();
         g = 0;
@@ -374,52 +385,51 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
 #pragma unroll
   for (int p = 0; p < 2; p++)
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++)
+    for (int ct = 0; ct < 2; ct++) {
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int c = 64 * wave + 32 * p + rowoff(r, hh);
-        lds[c * TT + 32 * ct + j] = gate(acc[2 * p][ct][r], acc[2 * p + 1][ct][r]);
+        const int c = 64 * mw + 32 * p + rowoff(r, hh);
+        lds[c * TT + 32 * ct + colbase] = gate(acc[2 * p][ct][r], acc[2 * p + 1][ct][r]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
-  // GEMM2 accumulators: res rows start from b_res + part_t (u = h + part_t re-enters the residual), skip rows from b_skip
+  // GEMM2 accumulators: res rows start from b_res + part_t (u = h + part_t re-enters the residual), skip rows from
+  // b_skip.  The pointers are laundered through an empty asm so these loads cannot be hoisted above the main loop.
+  {
+    const float *b2l = b2, *ptl = pt;
+    asm volatile("" : "+s"(b2l), "+s"(ptl));
 #pragma unroll
-  for (int rt = 0; rt < 4; rt++) {
-    const int obase = 128 * wave + 32 * rt;
+    for (int rt = 0; rt < 4; rt++) {
+      const int obase = 128 * mw + 32 * rt;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int o = obase + rowoff(r, hh);
-      float bv = b2[o];
-      if (obase < C) bv += pt[o];
+      for (int r = 0; r < 16; r++) {
+        const int o = obase + rowoff(r, hh);
+        float bv = b2l[o];
+        if (obase < C) bv += ptl[o];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+        for (int ct = 0; ct < 2; ct++) acc[rt][ct][r] = bv;
+      }
     }
   }
   __syncthreads();
 
-  const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)wave * G::NG2 * 4 * 64 + lane;
-#pragma unroll
-  for (int rt = 0; rt < 4; rt++) a_cur[rt] = ap2[rt * 64];
+  const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)mw * G::NG2 * 4 * 64 + lane;
+  load_a(a0, ap2, 0);
+  {
+    static_assert(G::NG2 % 2 == 0, "pair-unrolled loop");
 #pragma unroll 1
-  for (int Gi = 0; Gi < G::NG2; Gi++) {
-    {
-      const int Gn = (Gi + 1 < G::NG2) ? Gi + 1 : Gi;
-#pragma unroll
-      for (int rt = 0; rt < 4; rt++) a_nxt[rt] = ap2[(size_t)Gn * 256 + rt * 64];
+    for (int Gi = 0; Gi < G::NG2; Gi += 2) {
+      load_a(a1, ap2, Gi + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float *gb = lds + (Gi * 8 + hh) * TT + colbase;
+      mma4(a0, gb);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(a0, ap2, (Gi + 2 < G::NG2) ? Gi + 2 : Gi);
+      __builtin_amdgcn_sched_barrier(0);
+      mma4(a1, gb + 8 * TT);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int s = Gi * 4 + e;
-      float bv[4];
-#pragma unroll
-      for (int ct = 0; ct < 4; ct++) bv[ct] = lds[(2 * s + hh) * TT + 32 * ct + j];
-#pragma unroll
-      for (int rt = 0; rt < 4; rt++)
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rt][e], bv[ct], acc[rt][ct], 0, 0, 0);
-    }
-#pragma unroll
-    for (int rt = 0; rt < 4; rt++) a_cur[rt] = a_nxt[rt];
   }
 
   // epilogue (WaveNet.py:97, :133): 32-bit offsets from wave-uniform bases, one (rt, ct) tile at a time
@@ -428,12 +438,12 @@ __global__ __launch_bounds__(C / 64 * 64, 1) void resblock_f32_kernel(
   float *sk = skip + (size_t)b * C * L;     // S == C
 #pragma unroll
   for (int rt = 0; rt < 4; rt++) {
-    const int obase = 128 * wave + 32 * rt;
+    const int obase = 128 * mw + 32 * rt;
     const bool is_res = obase < C;          // wave-uniform
     const unsigned rbase = (unsigned)((is_res ? obase : obase - C) + 4 * hh) * (unsigned)L;
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) {
-      const int t = t0 + 32 * ct + j;
+    for (int ct = 0; ct < 2; ct++) {
+      const int t = t0 + 32 * ct + colbase;
       if (t < L) {
         if (is_res) {
 #pragma unroll
@@ -486,13 +496,13 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   }
   switch (C) {
     case 64:
-      resblock_f32_kernel<64><<<grid, 64, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      resblock_f32_kernel<64><<<grid, 128, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
       break;
     case 128:
-      resblock_f32_kernel<128><<<grid, 128, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      resblock_f32_kernel<128><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
       break;
     case 256:
-      resblock_f32_kernel<256><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      resblock_f32_kernel<256><<<grid, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
       break;
     default:
       set_error("resblock: unsupported res_channels %d (need 64, 128 or 256)", C);
