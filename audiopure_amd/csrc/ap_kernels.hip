@@ -80,7 +80,10 @@ __global__ void pack_w1_kernel(const float *__restrict__ w1f, float *__restrict_
 }
 
 // GEMM2 / final-conv A image: [wave][group][rowtile RT][lane][4], rows o = RT*32*wave + 32 rt + i, k = channel.
-__global__ void pack_rows_kernel(const float *__restrict__ wf, float *__restrict__ out, int M, int K, int RT) {
+// mode 1 (GEMM2, RT = 4): wf = [res rows (M/2); skip rows (M/2)]; wave w owns res rows [64w, 64w+64) in row tiles 0,1
+// and the skip rows of the same channels in row tiles 2,3.
+__global__ void pack_rows_kernel(const float *__restrict__ wf, float *__restrict__ out, int M, int K, int RT,
+                                 int mode) {
   const int NG = K / 8;
   const int NWv = M / (32 * RT);
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -96,6 +99,7 @@ __global__ void pack_rows_kernel(const float *__restrict__ wf, float *__restrict
   int s = 4 * G + e, hh = lane >> 5, i = lane & 31;
   int kk = 2 * s + hh;
   int o = 32 * RT * w + 32 * rt + i;
+  if (mode == 1) o = (rt >> 1) * (M / 2) + 64 * w + 32 * (rt & 1) + i;
   out[idx] = wf[(size_t)o * K + kk];
 }
 
@@ -140,14 +144,14 @@ int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st) {
     copy_to(b + bl.skip_b, ctx->b2 + (size_t)n * (C + S) + C, S, st);
     size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
     pack_w1_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(w1f, ctx->w1p + (size_t)n * n1, C);
-    pack_rows_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(w2f, ctx->w2p + (size_t)n * n2, C + S, C, 4);
+    pack_rows_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(w2f, ctx->w2p + (size_t)n * n2, C + S, C, 4, 1);
   }
   fold_one(blob + bl.f1_g, blob + bl.f1_v, ctx->norms, ctx->wf1f, S, S, st);
   copy_to(blob + bl.f1_b, ctx->bf1, S, st);
   copy_to(blob + bl.f2_w, ctx->wf2, S, st);
   copy_to(blob + bl.f2_b, ctx->bf2, 1, st);
   size_t nf = (size_t)S * S;
-  pack_rows_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, st>>>(ctx->wf1f, ctx->wf1p, S, S, 2);
+  pack_rows_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, st>>>(ctx->wf1f, ctx->wf1p, S, S, 2, 0);
   AP_HIP(hipGetLastError());
   return 0;
 }
@@ -256,7 +260,7 @@ template <int C>
 __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles) {
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int ablate) {
   using G = RBGeom<C>;
   constexpr int NT = G::NT;
   __shared__ float lds[G::LDS_FLOATS];
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
   // ahead of its use, ping-ponging between two named register sets so no copy or early wait is needed.
   auto load_a = [&](f32x4(&a)[4], const f32x4 *base, int Gi) {
 #pragma unroll
-    for (int rt = 0; rt < 4; rt++) a[rt] = base[(size_t)Gi * 256 + rt * 64];
+    for (int rt = 0; rt < 4; rt++) a[rt] = base[(size_t)((ablate & 4) ? 0 : Gi) * 256 + rt * 64];
   };
   auto mma4 = [&](const f32x4(&a)[4], const float *xb) {      // 4 k-steps: 8 LDS reads, 32 MFMAs
     float bv[4][2];
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
     int ch = 0, g = 0;
 #pragma unroll 1
     for (int Gi = 0; Gi < G::NG1; Gi += 2) {
-      if (g == 0 && ch + 1 < G::NCHUNK) issue_loads(ch + 1);
+      if (g == 0 && ch + 1 < G::NCHUNK && !(ablate & 8)) issue_loads(ch + 1);
       load_a(a1, ap, Gi + 1);
       __builtin_amdgcn_sched_barrier(0);
       const float *xb = lds + (ch & 1) * G::XBUF + (g * 8 + hh) * TT + colbase;
@@ -389,30 +393,53 @@ __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int c = 64 * mw + 32 * p + rowoff(r, hh);
-        lds[c * TT + 32 * ct + colbase] = gate(acc[2 * p][ct][r], acc[2 * p + 1][ct][r]);
+        lds[c * TT + 32 * ct + colbase] =
+            (ablate & 2) ? acc[2 * p][ct][r] : gate(acc[2 * p][ct][r], acc[2 * p + 1][ct][r]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
 
-  // GEMM2 accumulators: res rows start from b_res + part_t (u = h + part_t re-enters the residual), skip rows from
-  // b_skip.  The pointers are laundered through an empty asm so these loads cannot be hoisted above the main loop.
+  // GEMM2: row tiles 0,1 = res_conv rows of this wave's 64 channels, row tiles 2,3 = skip_conv rows of the same
+  // channels.  Accumulators start from b_res + part_t (u = h + part_t re-enters the residual) / b_skip.  The pointers
+  // are laundered through an empty asm so these loads cannot be hoisted above the main loop.
   {
     const float *b2l = b2, *ptl = pt;
     asm volatile("" : "+s"(b2l), "+s"(ptl));
 #pragma unroll
     for (int rt = 0; rt < 4; rt++) {
-      const int obase = 128 * mw + 32 * rt;
+      const int cb = 64 * mw + 32 * (rt & 1);
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int o = obase + rowoff(r, hh);
-        float bv = b2l[o];
-        if (obase < C) bv += ptl[o];
+        const int c = cb + rowoff(r, hh);
+        float bv = (rt < 2) ? b2l[c] + ptl[c] : b2l[C + c];
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) acc[rt][ct][r] = bv;
       }
     }
   }
   __syncthreads();
+
+  // The residual input h[c][t] of this wave's 64 x 64 patch is fetched now (64 VGPRs) and consumed after GEMM2,
+  // so the epilogue never waits on memory; the skip half needs no read at all (float atomics at the memory side).
+  float hres[2][2][16];
+  unsigned evoff[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      const int t = min(t0 + 32 * ct + colbase, L - 1);
+      evoff[rt][ct] = ((unsigned)(64 * mw + 32 * rt + 4 * hh) * (unsigned)L + (unsigned)t) * 4u;
+    }
+  if (!(ablate & 1)) {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          hres[rt][ct][r] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(hrs, evoff[rt][ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+  }
 
   const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)mw * G::NG2 * 4 * 64 + lane;
   load_a(a0, ap2, 0);
@@ -432,43 +459,36 @@ __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
     }
   }
 
-  // epilogue (WaveNet.py:97, :133): 32-bit offsets from wave-uniform bases, one (rt, ct) tile at a time
+  // epilogue (WaveNet.py:97, :133)
+  if (ablate & 1) return;
   const float RS = 0.707106781186547524f;   // float(math.sqrt(0.5))
   float *ho = hout + (size_t)b * C * L;
   float *sk = skip + (size_t)b * C * L;     // S == C
 #pragma unroll
   for (int rt = 0; rt < 4; rt++) {
-    const int obase = 128 * mw + 32 * rt;
-    const bool is_res = obase < C;          // wave-uniform
-    const unsigned rbase = (unsigned)((is_res ? obase : obase - C) + 4 * hh) * (unsigned)L;
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
       const int t = t0 + 32 * ct + colbase;
+      const unsigned rbase = (unsigned)(64 * mw + 32 * (rt & 1) + 4 * hh) * (unsigned)L + (unsigned)t;
       if (t < L) {
-        if (is_res) {
+        if (rt < 2) {
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const unsigned off = rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L + (unsigned)t;
-            ho[off] = (hin_b[off] + acc[rt][ct][r]) * RS;
-          }
+          for (int r = 0; r < 16; r++)
+            ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = (hres[rt][ct][r] + acc[rt][ct][r]) * RS;
         } else if (accumulate) {
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const unsigned off = rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L + (unsigned)t;
-            sk[off] = sk[off] + acc[rt][ct][r];
-          }
+          for (int r = 0; r < 16; r++)
+            unsafeAtomicAdd(&sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L], acc[rt][ct][r]);
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            const unsigned off = rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L + (unsigned)t;
-            sk[off] = acc[rt][ct][r];
-          }
+          for (int r = 0; r < 16; r++) sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = acc[rt][ct][r];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
+
+static int g_ablate = 0;   // timing-only ablation mask (ap_debug_ablate); 0 in every real run
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                     int accumulate, int B, int L, hipStream_t st) {
@@ -496,13 +516,13 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   }
   switch (C) {
     case 64:
-      resblock_f32_kernel<64><<<grid, 128, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      resblock_f32_kernel<64><<<grid, 128, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, g_ablate);
       break;
     case 128:
-      resblock_f32_kernel<128><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      resblock_f32_kernel<128><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, g_ablate);
       break;
     case 256:
-      resblock_f32_kernel<256><<<grid, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles);
+      resblock_f32_kernel<256><<<grid, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, g_ablate);
       break;
     default:
       set_error("resblock: unsupported res_channels %d (need 64, 128 or 256)", C);
@@ -716,6 +736,11 @@ __global__ void philox_fill_kernel(float *__restrict__ out, uint64_t seed, uint3
 }
 
 }  // namespace ap
+
+extern "C" int ap_debug_ablate(int mask) {
+  ap::g_ablate = mask;
+  return 0;
+}
 
 extern "C" int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                                 void *stream) {

@@ -1,0 +1,28 @@
+import sys, ctypes as C, torch
+sys.path.insert(0, ".")
+from audiopure_amd import synth, _native as N
+from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+dev = torch.device("cuda:0")
+cfg = dict(synth.FULL_WAVENET_CONFIG)
+net = WaveNet_Speech_Commands(**cfg).to(dev)
+eng = net.engine()
+lib = eng.lib
+B, L = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 16000
+h = torch.randn(B, 256, L, device=dev); ho = torch.empty_like(h); sk = torch.zeros_like(h)
+pt = torch.randn(256, device=dev)
+lib.ap_debug_ablate.argtypes = [C.c_int]
+def run(mask, layer, reps=5):
+    lib.ap_debug_ablate(mask)
+    for _ in range(2):
+        lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho), N.ptr(sk), 1, B, L, N.stream())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho), N.ptr(sk), 1, B, L, N.stream())
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return ms, 16.777e9 * B / ms / 1e9
+for layer in (0, 5, 11):
+    for mask in (0, 1, 2, 4, 8, 3, 7, 15):
+        ms, tf = run(mask, layer)
+        print(f"layer {layer:2d} mask {mask:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s-equivalent", flush=True)
