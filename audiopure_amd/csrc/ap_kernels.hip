@@ -236,10 +236,10 @@ int launch_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, hipStr
 // ---------------------------------------------------------------------------------------------
 // fused residual block, exact fp32 MFMA
 // ---------------------------------------------------------------------------------------------
-template <int C>
+template <int C, int TTK>
 struct RBGeom {
   static constexpr int NWM = C / 64;           // wave rows: wave (mw, nw) owns gate channels [64mw, 64mw+64) ...
-  static constexpr int NWN = 2;                // ... and time columns [64nw, 64nw+64) of the 128-sample tile
+  static constexpr int NWN = TTK / 64;         // ... and time columns [64nw, 64nw+64) of the TTK-sample tile
   static constexpr int NW = NWM * NWN;
   static constexpr int NT = NW * 64;           // 512 threads at C = 256: two waves per SIMD
   static constexpr int ROWS = 3 * KC;          // staged K rows per chunk (3 taps x 16 channels)
@@ -247,28 +247,29 @@ struct RBGeom {
   static constexpr int GPC = ROWS / 8;         // A groups (4 k-steps of 2) per chunk = 6
   static constexpr int NG1 = NCHUNK * GPC;     // = 3C/8
   static constexpr int NG2 = C / 8;
-  static constexpr int EPT = ROWS * TT / NT;   // staged elements per thread per chunk (12 at C = 256)
-  static constexpr int RPI = NT / 128;         // rows advanced per element index
+  static constexpr int EPT = ROWS * TTK / NT;   // staged elements per thread per chunk (12 at C = 256)
+  static constexpr int RPI = NT / TTK;         // rows advanced per element index
   static constexpr int NPT = KC / RPI;         // distinct channels per thread per chunk
-  static constexpr int XBUF = ROWS * TT;       // floats per X buffer
-  static constexpr int LDS_FLOATS = (2 * XBUF > C * TT) ? 2 * XBUF : C * TT;
+  static constexpr int XBUF = ROWS * TTK;      // floats per X buffer
+  static constexpr int LDS_FLOATS = (2 * XBUF > C * TTK) ? 2 * XBUF : C * TTK;
 };
 
 // One workgroup = one (utterance, 128-sample tile).  Per wave: 128 GEMM rows x 64 columns = 8 accumulator tiles of
 // 32x32 (128 AGPRs), so two waves share each SIMD and one wave's waits/VALU phases overlap the other's MFMAs.
-template <int C>
-__global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
+template <int C, int TTK>
+__global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2p,
     const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int ablate) {
-  using G = RBGeom<C>;
+  using G = RBGeom<C, TTK>;
+  constexpr int TT = TTK;   // time tile of this kernel (shadows ap::TT)
   constexpr int NT = G::NT;
   __shared__ float lds[G::LDS_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mw = wave >> 1, nw = wave & 1;
+  const int mw = wave / G::NWN, nw = wave % G::NWN;
   const int j = lane & 31, hh = lane >> 5;
   const int b = __builtin_amdgcn_readfirstlane(blockIdx.x / ntiles);
   const int t0 = __builtin_amdgcn_readfirstlane((blockIdx.x % ntiles) * TT);
@@ -295,14 +296,14 @@ __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
 
   // ---- staging of X = [tap][c_local][t] chunks through registers: buffer loads with 32-bit offsets issued at
   // the head of a chunk, FiLM add + zero-pad select + ds_write at its tail (one barrier per chunk).
-  // Element i of a thread sits at LDS index i*NT + tid = (row i*RPI + rsel, col tid & 127).
+  // Element i of a thread sits at LDS index i*NT + tid = (row i*RPI + rsel, col tid % TT).
   constexpr int RPI = G::RPI, NPT = G::NPT;
-  const int rsel = tid >> 7;
+  const int rsel = tid / TT;
   unsigned voff[3];
   bool tok[3];
 #pragma unroll
   for (int tap = 0; tap < 3; tap++) {
-    const int tp = t0 + (tid & 127) + (tap - 1) * d;
+    const int tp = t0 + (tid & (TT - 1)) + (tap - 1) * d;
     tok[tap] = (tp >= 0) && (tp < L);
     voff[tap] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)rsel * (unsigned)L) * 4u;
   }
@@ -488,18 +489,17 @@ __global__ __launch_bounds__(C / 64 * 128, 2) void resblock_f32_kernel(
   }
 }
 
+static int g_tile = 64;    // time tile of the residual-block kernel: 128 (8 waves, 1 WG/CU) or 64 (4 waves, 2 WG/CU)
 static int g_ablate = 0;   // timing-only ablation mask (ap_debug_ablate); 0 in every real run
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                     int accumulate, int B, int L, hipStream_t st) {
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
-  const int ntiles = (L + TT - 1) / TT;
   const float *w1p = ctx->w1p + (size_t)layer * 2 * C * C * 3;
   const float *w2p = ctx->w2p + (size_t)layer * (C + S) * C;
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
-  unsigned grid = (unsigned)B * ntiles;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (ctx->profile) {
     if (ctx->ev_used + 2 > ctx->ev.size()) {
@@ -514,20 +514,21 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
     ctx->ev_used += 2;
     AP_HIP(hipEventRecord(ev0, st));
   }
-  switch (C) {
-    case 64:
-      resblock_f32_kernel<64><<<grid, 128, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, g_ablate);
-      break;
-    case 128:
-      resblock_f32_kernel<128><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, g_ablate);
-      break;
-    case 256:
-      resblock_f32_kernel<256><<<grid, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, g_ablate);
-      break;
-    default:
-      set_error("resblock: unsupported res_channels %d (need 64, 128 or 256)", C);
-      return -22;
+#define AP_RB(CC, TK)                                                                                              \
+  resblock_f32_kernel<CC, TK><<<(unsigned)B * ((L + TK - 1) / TK), CC / 64 * TK, 0, st>>>(                         \
+      hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, (L + TK - 1) / TK, g_ablate)
+  const int tk = g_tile;
+  if (C == 64 && tk == 64) AP_RB(64, 64);
+  else if (C == 64) AP_RB(64, 128);
+  else if (C == 128 && tk == 64) AP_RB(128, 64);
+  else if (C == 128) AP_RB(128, 128);
+  else if (C == 256 && tk == 64) AP_RB(256, 64);
+  else if (C == 256) AP_RB(256, 128);
+  else {
+    set_error("resblock: unsupported res_channels %d (need 64, 128 or 256)", C);
+    return -22;
   }
+#undef AP_RB
   if (ev1) AP_HIP(hipEventRecord(ev1, st));
   AP_HIP(hipGetLastError());
   return 0;
@@ -736,6 +737,12 @@ __global__ void philox_fill_kernel(float *__restrict__ out, uint64_t seed, uint3
 }
 
 }  // namespace ap
+
+extern "C" int ap_debug_tile(int tile) {
+  if (tile != 64 && tile != 128) return -22;
+  ap::g_tile = tile;
+  return 0;
+}
 
 extern "C" int ap_debug_ablate(int mask) {
   ap::g_ablate = mask;

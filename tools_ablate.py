@@ -11,6 +11,7 @@ B, L = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 16000
 h = torch.randn(B, 256, L, device=dev); ho = torch.empty_like(h); sk = torch.zeros_like(h)
 pt = torch.randn(256, device=dev)
 lib.ap_debug_ablate.argtypes = [C.c_int]
+if len(sys.argv) > 2: print('tile', sys.argv[2], lib.ap_debug_tile(int(sys.argv[2])))
 def run(mask, layer, reps=5):
     lib.ap_debug_ablate(mask)
     for _ in range(2):
@@ -22,7 +23,7 @@ def run(mask, layer, reps=5):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return ms, 16.777e9 * B / ms / 1e9
-for layer in (0, 5, 11):
+for layer in (5,):
     for mask in (0, 1, 2, 4, 8, 3, 7, 15):
         ms, tf = run(mask, layer)
         print(f"layer {layer:2d} mask {mask:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s-equivalent", flush=True)
