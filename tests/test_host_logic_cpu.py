@@ -1,0 +1,97 @@
+"""Host-side logic of the reference-shaped classes that needs no GPU: coefficient tables of the sampling chains,
+state-dict compatibility with the reference's key names, loud failure without a device."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from audiopure_amd import synth
+from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import (calc_diffusion_hyperparams,
+                                                                      calc_diffusion_step_embedding)
+from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+from audiopure_amd.diffusion_models.diffwave_sde import RevVPSDE
+from audiopure_amd.acoustic_system import AcousticSystem
+from audiopure_amd.audio_models.M5.M5Net import M5
+from audiopure_amd import _native as N
+
+
+def test_schedule_and_embedding_match_reference_golden(golden):
+    dh = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    for k in ("Beta", "Alpha", "Alpha_bar", "Sigma"):
+        assert np.array_equal(dh[k].numpy(), golden[f"sched/{k}"])
+    e = calc_diffusion_step_embedding(torch.from_numpy(golden["embed/steps"]), 128)
+    assert np.array_equal(e.numpy(), golden["embed/out"])
+
+
+def test_state_dict_keys_are_the_references():
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net = WaveNet_Speech_Commands(**cfg)
+    ref_sd = synth.wavenet_state_dict(cfg, 0)          # reference key names / shapes (probe)
+    assert list(net.state_dict().keys()) == list(ref_sd.keys()) and len(ref_sd) == 408
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == ref_sd[k].shape, k
+    assert sum(p.numel() for p in net.parameters()) == 24071681
+    m5 = M5(n_input=1, n_output=10)
+    assert m5._get_name() == "M5" and sum(p.numel() for p in m5.parameters()) == 25290
+
+
+def test_ddpm_chain_coefficients():
+    dh = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    net = WaveNet_Speech_Commands(**synth.mini_wavenet_config(64, 2, 2))
+    dw = DiffWave(net, dh, reverse_timestep=5)
+    steps = dw._ddpm_steps(5)
+    assert [s[0] for s in steps] == [4.0, 3.0, 2.0, 1.0, 0.0] and [s[4] for s in steps] == [1, 2, 3, 4, 0]
+    for (t, ca, cb, cs, _), tt in zip(steps, range(4, -1, -1)):
+        a, ab = float(dh["Alpha"][tt]), float(dh["Alpha_bar"][tt])
+        assert math.isclose(ca, 1 / math.sqrt(a), rel_tol=1e-12)
+        assert math.isclose(cb, -(1 - a) / math.sqrt(1 - ab) / math.sqrt(a), rel_tol=1e-12)
+        assert cs == (float(dh["Sigma"][tt]) if tt > 0 else 0.0)
+
+
+def test_sde_euler_coefficients_are_first_order_ddpm():
+    dh = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    sde = RevVPSDE(model=None, score_type="guided_diffusion", beta_min=0.0001 * 200, beta_max=0.02 * 200, N=200)
+    for (k, ca, cb, cs, draw), i in zip(sde.euler_steps(10), range(10)):
+        kk = int(k)
+        assert kk == 9 - i and draw == 1 + i
+        beta = float(sde.discrete_betas[kk])
+        assert math.isclose(ca, 1 + beta / 2) and math.isclose(cb, -beta / math.sqrt(1 - float(sde.alphas_cumprod[kk])))
+        # same sigma as DDPM up to the cumprod-vs-loop table difference
+        assert abs(cs - (float(dh["Sigma"][kk]) if kk > 0 else 0.0)) < 1e-6
+        a = float(dh["Alpha"][kk])
+        assert abs(ca - 1 / math.sqrt(a)) < 2e-4 * beta * 100
+
+
+def test_no_device_no_fallback():
+    net = WaveNet_Speech_Commands(**synth.mini_wavenet_config(64, 2, 2))
+    with pytest.raises(N.NativeError):
+        net((torch.zeros(1, 1, 256), torch.zeros(1, 1)))
+    with pytest.raises(N.NativeError):
+        M5(n_output=10).eval()(torch.zeros(1, 1, 16000))
+    with pytest.raises(NotImplementedError):
+        AcousticSystem(classifier=torch.nn.Identity(), transform=None, defender=None, defense_type="nope")
+    with pytest.raises(NotImplementedError):
+        M5(n_output=10)(torch.zeros(1, 1, 16000))       # training mode
+    with pytest.raises(TypeError):
+        DiffWave(torch.nn.Identity(), {}, 5)
+
+
+def test_acoustic_system_dispatch_order():
+    calls = []
+
+    class Rec(torch.nn.Module):
+        def __init__(self, name):
+            super().__init__()
+            self.name = name
+
+        def forward(self, x):
+            calls.append(self.name)
+            return x
+
+    AcousticSystem(Rec("cls"), Rec("tr"), Rec("def"), "wave")(torch.zeros(1), True)
+    AcousticSystem(Rec("cls"), Rec("tr"), Rec("def"), "spec")(torch.zeros(1), True)
+    AcousticSystem(Rec("cls"), None, Rec("def"), "wave")(torch.zeros(1), False)
+    assert calls == ["def", "tr", "cls", "tr", "def", "cls", "cls"]      # acoustic_system.py:35-51

@@ -1,0 +1,57 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard plan + score gather, with per-clip values that depend only
+on the GLOBAL utterance index (the numpy Philox oracle), so the gathered result must equal the 1-process result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from audiopure_amd.sharding import all_gather_scores, shard_bounds
+from oracle.philox import philox_normal
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 512, 4096, 4099):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _scores(start, stop, K=10):
+    # stand-in for per-clip log-probs: a function of the global utterance index only
+    return torch.from_numpy(philox_normal(77, 0, start, stop - start, K)) if stop > start else torch.zeros((0, K))
+
+
+def _worker(rank, world, port, n_total, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, e = shard_bounds(n_total, rank, world)
+    got = all_gather_scores(_scores(s, e), n_total)
+    if rank == 0:
+        np.save(out, got.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7])
+def test_world2_gather_equals_single_process(tmp_path, n_total):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_worker, args=(2, port, n_total, out), nprocs=2, join=True)
+    assert np.array_equal(np.load(out), _scores(0, n_total).numpy())
+
+
+def test_single_process_passthrough():
+    x = torch.arange(12.0).view(4, 3)
+    assert all_gather_scores(x, 4) is x
