@@ -62,6 +62,16 @@ def cpu_baseline(budget_s: float = 25.0):
                       f"5-step metric"}
 
 
+def pmc_traffic(B):
+    """HBM-side bytes per residual-block launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 calibration, + WRITE_SIZE), scaled from the 512-clip launch it was measured on; None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        return round(d["traffic_bytes_per_launch"] * B / 512.0)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,7 +169,7 @@ def main():
                        "parallelism": f"utterance-sharded x{world}, logits all_gather"},
             "roofline": {"bound": "mfma", "kernel": "resblock_f32_kernel<256,64>",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
                          "launches": int(launches.value), "avg_launch_ms": round(k_ms, 4),
                          "flop_per_launch": FLOP_PER_LAYER_UTT * B,
                          "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
