@@ -64,8 +64,12 @@ static int check_cfg(const ap_config &c) {
     set_error("config: invalid layer/embedding/schedule sizes");
     return -22;
   }
-  if (c.precision != AP_PREC_F32) {
-    set_error("config: precision %d not built (AP_PREC_F32 only in this build)", c.precision);
+  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16) {
+    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16)", c.precision);
+    return -22;
+  }
+  if (c.precision == AP_PREC_BF16 && c.res_channels != 256) {
+    set_error("config: AP_PREC_BF16 is built for res_channels = 256 only (got %d)", c.res_channels);
     return -22;
   }
   return 0;
@@ -93,6 +97,8 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->C = cfg->res_channels; c->S = cfg->skip_channels; c->NL = cfg->num_res_layers; c->NW = c->C / 64;
   c->loaded = false;
   c->slab = nullptr;
+  c->slab_bf = nullptr;
+  c->w1p_bf = c->w2p_bf = nullptr;
   c->profile = false;
   c->ev_used = 0;
   const int T = cfg->T;
@@ -122,6 +128,7 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
 extern "C" int ap_ctx_destroy(ap_ctx *ctx) {
   if (!ctx) return 0;
   if (ctx->slab) (void)hipFree(ctx->slab);
+  if (ctx->slab_bf) (void)hipFree(ctx->slab_bf);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
@@ -218,6 +225,16 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
   AP_HIP(hipMemcpyAsync(ctx->emb_freq, embed_freq_dev, sizeof(float) * (Ein / 2), hipMemcpyDeviceToDevice, st));
   int rc = launch_fold_and_pack(ctx, blob_dev, st);
   if (rc) return rc;
+  if (c.precision == AP_PREC_BF16) {
+    const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
+    if (!ctx->slab_bf) {
+      AP_HIP(hipMalloc(&ctx->slab_bf, (n1 + n2) * 2));
+      ctx->w1p_bf = ctx->slab_bf;
+      ctx->w2p_bf = (char *)ctx->slab_bf + n1 * 2;
+    }
+    rc = launch_pack_bf16(ctx, st);
+    if (rc) return rc;
+  }
   AP_HIP(hipStreamSynchronize(st));
   ctx->loaded = true;
   return 0;

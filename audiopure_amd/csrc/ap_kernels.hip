@@ -490,10 +490,29 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
 }
 
 static int g_tile = 64;    // time tile of the residual-block kernel: 128 (8 waves, 1 WG/CU) or 64 (4 waves, 2 WG/CU)
+static int g_force_f32 = 0;  // debug: run the fp32 kernel even in a bf16 context (A/B timing in one process)
 static int g_ablate = 0;   // timing-only ablation mask (ap_debug_ablate); 0 in every real run
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                     int accumulate, int B, int L, hipStream_t st) {
+  if (ctx->cfg.precision == AP_PREC_BF16 && !g_force_f32) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profile) {
+      if (ctx->ev_used + 2 > ctx->ev.size())
+        for (int i = 0; i < 2; i++) {
+          hipEvent_t e;
+          AP_HIP(hipEventCreate(&e));
+          ctx->ev.push_back(e);
+        }
+      e0 = ctx->ev[ctx->ev_used];
+      e1 = ctx->ev[ctx->ev_used + 1];
+      ctx->ev_used += 2;
+      AP_HIP(hipEventRecord(e0, st));
+    }
+    int rc = launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+    if (e1) AP_HIP(hipEventRecord(e1, st));
+    return rc;
+  }
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const float *w1p = ctx->w1p + (size_t)layer * 2 * C * C * 3;
@@ -741,6 +760,11 @@ __global__ void philox_fill_kernel(float *__restrict__ out, uint64_t seed, uint3
 extern "C" int ap_debug_tile(int tile) {
   if (tile != 64 && tile != 128) return -22;
   ap::g_tile = tile;
+  return 0;
+}
+
+extern "C" int ap_debug_force_f32(int on) {
+  ap::g_force_f32 = on;
   return 0;
 }
 

@@ -146,6 +146,15 @@ class WaveNet_Speech_Commands(nn.Module):
         self._precision = N.AP_PREC_F32
 
     # ---- native plumbing ------------------------------------------------------------------
+    def set_precision(self, mode: str):
+        """"f32": exact fp32 MFMA (default, the reference's arithmetic).  "bf16": bf16 MFMA operands, fp32 accumulate
+        and storage (BASELINE configs[3]); only for res_channels = 256."""
+        prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16}[mode]
+        if prec != self._precision:
+            self._precision = prec
+            self._engine = None
+        return self
+
     def _blob_tensors(self):
         r = self.residual_layer
         ic, f0, f2 = self.init_conv[0].conv, self.final_conv[0].conv, self.final_conv[2].conv

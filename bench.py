@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
     ap.add_argument("--reverse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
+    ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     args = ap.parse_args()
 
     import torch
@@ -108,6 +111,7 @@ def main():
     net = WaveNet_Speech_Commands(**cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(cfg, 0).items()})
     net = net.to(dev)
+    net.set_precision(args.precision)
     dw = DiffWave(model=net, diffusion_hyperparams=calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG),
                   reverse_timestep=n)
     dw.set_noise_source(("philox", 1234, rank * B))              # global utterance index = rank*B + b
@@ -158,22 +162,30 @@ def main():
         value = world * B * args.steps / elapsed
         k_ms = tot_ms.value / max(launches.value, 1)
         achieved = FLOP_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e12
+        if args.precision == "f32":
+            roof = {"bound": "mfma", "kernel": "resblock_f32_kernel<256,64>", "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": pmc_traffic(B)}
+        else:
+            gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "resblock_bf16_kernel<256>", "achieved": round(gbs, 1), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                    "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
+        roof.update({"launches": int(launches.value), "avg_launch_ms": round(k_ms, 4),
+                     "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,
+                     "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
+                     "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)})
         out = {
             "metric": "purified 1s@16kHz utterances/sec at 5 reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"DiffWave DDPM purify n={n} + M5 classify, batch={B}/GPU, 1 s @ 16 kHz clips, "
-                                   "fp32 (BASELINE.json configs[1]); shipped config C=S=256, 36 layers",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"DiffWave {args.sampler.upper()} purify n={n} + M5 classify, batch={B}/GPU, 1 s @ 16 kHz "
+                                   f"clips, {args.precision} (BASELINE.json configs[{1 if args.precision == 'f32' else 3}]); "
+                                   "shipped config C=S=256, 36 layers",
                        "global_batch": world * B, "clip_samples": L, "reverse_steps": n,
                        "parallelism": f"utterance-sharded x{world}, logits all_gather"},
-            "roofline": {"bound": "mfma", "kernel": "resblock_f32_kernel<256,64>",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(B),
-                         "launches": int(launches.value), "avg_launch_ms": round(k_ms, 4),
-                         "flop_per_launch": FLOP_PER_LAYER_UTT * B,
-                         "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
-                         "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

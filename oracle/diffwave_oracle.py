@@ -86,25 +86,34 @@ def _swish(x):
 # --------------------------------------------------------------------------
 # epsilon network   (WaveNet.py:53-172)
 # --------------------------------------------------------------------------
-def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor):
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    """Round-to-nearest-even to bfloat16 and back: what the AP_PREC_BF16 kernels feed the matrix cores."""
+    return t.to(torch.bfloat16).float()
+
+
+def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor, bf16_operands: bool = False):
     """One ``Residual_block.forward`` (WaveNet.py:75-97).
 
     NB the reference's ``h += part_t`` aliases the block input (``h = x`` at :77,
     in-place add at :84), so the residual branch is ``(x + part_t + res) * sqrt(.5)``.
+    ``bf16_operands`` emulates the bf16 mode of the HIP path: both GEMMs see bf16-rounded operands
+    (u, W_dil, g, W_res, W_skip), products/accumulation and everything else stay fp32.
     """
     p = f"residual_layer.residual_blocks.{n}"
+    q = _bf16 if bf16_operands else (lambda t: t)
     B, C, L = x.shape
     part_t = F.linear(emb, w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).view(B, C, 1)    # :82-83
     u = x + part_t                                                                       # :84 (alias!)
-    h = F.conv1d(u, w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"],
+    h = F.conv1d(q(u), q(w[p + ".dilated_conv_layer.conv.weight"]), w[p + ".dilated_conv_layer.conv.bias"],
                  dilation=dilation, padding=dilation)                                    # :87, :26-27
     out = torch.tanh(h[:, :C, :]) * torch.sigmoid(h[:, C:, :])                           # :90
-    res = F.conv1d(out, w[p + ".res_conv.weight"], w[p + ".res_conv.bias"])              # :93
-    skip = F.conv1d(out, w[p + ".skip_conv.weight"], w[p + ".skip_conv.bias"])           # :95
+    res = F.conv1d(q(out), q(w[p + ".res_conv.weight"]), w[p + ".res_conv.bias"])        # :93
+    skip = F.conv1d(q(out), q(w[p + ".skip_conv.weight"]), w[p + ".skip_conv.bias"])     # :95
     return (u + res) * math.sqrt(0.5), skip                                              # :97
 
 
-def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict | None = None) -> torch.Tensor:
+def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict | None = None,
+            bf16_operands: bool = False) -> torch.Tensor:
     """``WaveNet_Speech_Commands.forward((audio, diffusion_steps))`` (WaveNet.py:164-172).
 
     w: folded weights (``fold_state_dict``); x: [B,1,L]; steps: float [B,1].
@@ -118,7 +127,7 @@ def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict
     emb = _swish(F.linear(emb, w["residual_layer.fc_t2.weight"], w["residual_layer.fc_t2.bias"]))   # :126
     skip = 0
     for n in range(N):                                                                   # :131-133
-        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb)
+        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb, bf16_operands)
         skip = skip + skip_n
         if taps is not None:
             taps[f"h{n}"] = h

@@ -305,3 +305,50 @@ def test_errors_are_loud(mini, dh, dev):
     # numpy input is accepted like the reference (diffwave_ddpm.py:38-39)
     out = dw(x.cpu().numpy())
     assert out.shape == x.shape and out.is_cuda
+
+
+# ---- AP_PREC_BF16 (BASELINE configs[3]): bf16 MFMA operands, fp32 accumulate / storage -------------------------
+@pytest.mark.parametrize("L,layer", [(2048, 0), (1500, 5), (4133, 11), (130, 3)])
+def test_bf16_resblock_matches_bf16_emulating_oracle(dev, L, layer):
+    """Tight check of the bf16 kernel's logic: the oracle rounds the same GEMM operands to bf16 (RNE) and keeps
+    fp32 products/accumulation, so only summation order and bf16 rounding-boundary flips of g differ."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    net.set_precision("bf16")
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    B, C_ = 2, 256
+    h = torch.from_numpy(synth.uniform(f"hb/{L}", (B, C_, L), 1, -1.5, 1.5))
+    skip0 = torch.from_numpy(synth.uniform(f"sb/{L}", (B, C_, L), 1, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    with torch.no_grad():
+        p = f"residual_layer.residual_blocks.{layer}"
+        part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        h_q, s_q = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb, bf16_operands=True)
+        h_f, s_f = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb)
+    hd, sk = h.to(dev), skip0.to(dev).clone()
+    hout = torch.empty_like(hd)
+    pt = part_t.to(dev).contiguous()
+    N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
+    assert rel_err(hout.cpu().numpy(), h_q.numpy()) < 2e-3
+    assert rel_err((sk.cpu() - skip0).numpy(), s_q.numpy()) < 4e-3
+    # and the distance to the exact fp32 block is the bf16 operand rounding, reported tolerance 3e-2 of max
+    assert rel_err(hout.cpu().numpy(), h_f.numpy()) < 3e-2
+    assert rel_err((sk.cpu() - skip0).numpy(), s_f.numpy()) < 3e-2
+
+
+def test_bf16_full_chain_close_to_fp32_reference(golden, dev, dh):
+    """Whole shipped-config DDPM n=5 + M5 in bf16 mode vs the reference's fp32 golden vectors: stated bf16
+    tolerance 5e-2 of max|x| on the purified clip, same argmax."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, _ = _net(cfg, dev)
+    net.set_precision("bf16")
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=5)
+    dw.set_noise_source([torch.from_numpy(synth.noise(d, 2, 16000, seed=1234)) for d in range(5)])
+    xp = dw(torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev))
+    err = rel_err(xp.cpu().numpy(), golden["full/ddpm_n5/x"])
+    print("bf16 chain rel err vs fp32 reference:", err)
+    assert err < 5e-2
