@@ -768,8 +768,11 @@ extern "C" int ap_debug_force_f32(int on) {
   return 0;
 }
 
+namespace ap { extern int g_ablate_bf16; }
+
 extern "C" int ap_debug_ablate(int mask) {
   ap::g_ablate = mask;
+  ap::g_ablate_bf16 = mask;
   return 0;
 }
 

@@ -86,7 +86,7 @@ template <int C>
 __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const __bf16 *__restrict__ w1p, const float *__restrict__ b1, const __bf16 *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk) {
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk, int ablate) {
   constexpr int NW = C / 32, NT = NW * 64, NCH = C / BKC;
   static_assert(NT == 512, "bf16 kernel is built for C = 256 (8 waves)");
   constexpr int GSTRIDE = C + 8;                               // bf16 per column row of the g image (528 B)
@@ -163,6 +163,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   issue_loads(0);
   store_chunk(lds);
   __syncthreads();
+  const u32x4 *ap0 = reinterpret_cast<const u32x4 *>(w1p) + lane;
 
   // ---- GEMM1: per chunk 6 k-steps; A fragments (weights, this wave's 64 rows only) stream from L2 into registers in
   // sets of 3 k-steps, one set ahead of use.
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 #pragma unroll
     for (int s = 0; s < 3; s++)
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++) a[s][rt] = __builtin_bit_cast(bf16x8, base[(s * 2 + rt) * 64]);
+      for (int rt = 0; rt < 2; rt++)
+        a[s][rt] = __builtin_bit_cast(bf16x8, ((ablate & 4) ? ap0 : base)[(s * 2 + rt) * 64]);
   };
   auto mma3 = [&](const bf16x8(&a)[3][2], const unsigned char *xb, int rowbytes) {
 #pragma unroll
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   const int rdoff = (j * XSTRIDE + 8 * hh) * 2;                // this lane's B-fragment byte offset inside an X buffer
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ch++) {
-    if (ch + 1 < NCH) issue_loads(ch + 1);
+    if (ch + 1 < NCH && !(ablate & 8)) issue_loads(ch + 1);
     load_a3(a1, ap + (size_t)(ch * 6 + 3) * 128);
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char *xb = lds + (ch & 1) * XBYTES + rdoff;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     for (int qq = 0; qq < 4; qq++) {
       bf16x4 pk;
 #pragma unroll
-      for (int e = 0; e < 4; e++) pk[e] = (__bf16)gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
+      for (int e = 0; e < 4; e++)
+        pk[e] = (__bf16)((ablate & 2) ? acc[0][ct][4 * qq + e] : gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]));
       *reinterpret_cast<bf16x4 *>(lds + ((32 * ct + j) * GSTRIDE + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -222,20 +225,15 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 
   __syncthreads();
 
-  // residual patch of this wave (32 channels x 128 columns) fetched now, consumed after the res pass of GEMM2
-  float hres[4][16];
+  // per-lane element offsets of this wave's 32-channel x 128-column output patch (same for h, h' and skip)
   unsigned evoff[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
     const int t = min(t0 + 32 * ct + j, L - 1);
     evoff[ct] = ((unsigned)(32 * wave + 4 * hh) * (unsigned)L + (unsigned)t) * 4u;
   }
-#pragma unroll
-  for (int ct = 0; ct < 4; ct++)
-#pragma unroll
-    for (int r = 0; r < 16; r++)
-      hres[ct][r] = __builtin_bit_cast(
-          float, __builtin_amdgcn_raw_buffer_load_b32(hrs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(skip + (size_t)b * C * L), 0, (int)((unsigned)C * (unsigned)L * 4u), 0x00020000);
 
   // ---- GEMM2 in two passes of 32 rows x 128 columns (64 accumulator VGPRs each, so the residual patch fits beside
   // them): pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip.  (WaveNet.py:93-97, :133)
@@ -249,6 +247,17 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   asm volatile("" : "+s"(b2l), "+s"(ptl));
   auto gemm2_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
+    // the values this pass adds into (h for the residual, running skip) are fetched before its GEMM and consumed
+    // after it: 64 VGPRs, no exposed latency, and no float atomics (their ~1.3 TB/s chip-wide rate would cap the launch)
+    float pre[4][16];
+    if ((pass == 0 || accumulate) && !(ablate & 1)) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          pre[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+    }
     f32x16 ac[4];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -291,15 +300,15 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     for (int ct = 0; ct < 4; ct++) {
       const int t = t0 + 32 * ct + j;
       const unsigned rbase = (unsigned)(32 * wave + 4 * hh) * (unsigned)L + (unsigned)t;
-      if (t < L) {
+      if (t < L && !(ablate & 1)) {
         if (pass == 0) {
 #pragma unroll
           for (int r = 0; r < 16; r++)
-            ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = (hres[ct][r] + ac[ct][r]) * RS;
+            ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = (pre[ct][r] + ac[ct][r]) * RS;
         } else if (accumulate) {
 #pragma unroll
           for (int r = 0; r < 16; r++)
-            unsafeAtomicAdd(&sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L], ac[ct][r]);
+            sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = pre[ct][r] + ac[ct][r];
         } else {
 #pragma unroll
           for (int r = 0; r < 16; r++) sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = ac[ct][r];
@@ -311,6 +320,8 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   __builtin_amdgcn_sched_barrier(0);
   gemm2_pass(std::integral_constant<int, 1>{});
 }
+
+int g_ablate_bf16 = 0;
 
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st) {
@@ -327,7 +338,7 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
   resblock_bf16_kernel<256><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate,
-                                                            ntiles, nblk);
+                                                            ntiles, nblk, g_ablate_bf16);
   AP_HIP(hipGetLastError());
   return 0;
 }

@@ -103,7 +103,8 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run even N=1 exercises RCCL
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     B, L, n = args.batch, 16000, args.reverse_steps
@@ -129,12 +130,12 @@ def main():
 
     def step():
         lp = system(x0, True)
-        if world > 1:
+        if use_dist:
             return all_gather_scores(lp, world * B)         # the path's only collective: [B,10] scores / rank
         return lp
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -152,7 +153,7 @@ def main():
     N.check(eng.lib.ap_profile_read(eng.ctx, C.byref(tot_ms), C.byref(launches)))
     N.check(eng.lib.ap_profile_enable(eng.ctx, 0))
     assert torch.isfinite(lp).all()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -190,7 +191,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

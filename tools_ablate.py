@@ -5,6 +5,7 @@ from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNe
 dev = torch.device("cuda:0")
 cfg = dict(synth.FULL_WAVENET_CONFIG)
 net = WaveNet_Speech_Commands(**cfg).to(dev)
+if len(sys.argv) > 3: net.set_precision(sys.argv[3])
 eng = net.engine()
 lib = eng.lib
 B, L = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 16000
