@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char *what);
   } while (0)
 
 constexpr int TT = 128;   // time-tile (samples) of the fused kernels
-constexpr int KC = 16;    // channels per staged K-chunk of the dilated conv (x3 taps = 48 K rows)
+constexpr int KC = 32;    // channels per staged K-chunk of the dilated conv (x3 taps = 96 K rows)
 
 // Offsets (in floats) of the reference state-dict tensors inside the weight blob.
 struct BlobLayout {
