@@ -120,7 +120,13 @@ def main():
     import numpy as np
     m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
     m5 = m5.to(dev).eval()
-    system = AcousticSystem(classifier=m5, transform=None, defender=dw, defense_type="wave")
+    defender = dw
+    if args.sampler == "sde":                                    # BASELINE configs[3]: RevDiffWave VP-SDE Euler chain
+        import types
+        from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+        defender = RevDiffWave.from_model(dw, types.SimpleNamespace(
+            t=n, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1))
+    system = AcousticSystem(classifier=m5, transform=None, defender=defender, defense_type="wave")
     # synthetic 0.5*U(-1,1) clips, generated on device (resident in HBM before timing)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -177,7 +183,7 @@ def main():
                      "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
                      "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)})
         out = {
-            "metric": "purified 1s@16kHz utterances/sec at 5 reverse steps",
+            "metric": f"purified 1s@16kHz utterances/sec at {n} reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",

@@ -8,7 +8,8 @@ net = WaveNet_Speech_Commands(**cfg).to(dev)
 if len(sys.argv) > 3: net.set_precision(sys.argv[3])
 eng = net.engine()
 lib = eng.lib
-B, L = int(sys.argv[1]) if len(sys.argv) > 1 else 64, 16000
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+L = int(sys.argv[4]) if len(sys.argv) > 4 else 16000
 h = torch.randn(B, 256, L, device=dev); ho = torch.empty_like(h); sk = torch.zeros_like(h)
 pt = torch.randn(256, device=dev)
 lib.ap_debug_ablate.argtypes = [C.c_int]
@@ -24,7 +25,8 @@ def run(mask, layer, reps=5):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return ms, 16.777e9 * B / ms / 1e9
+if len(sys.argv) > 5: lib.ap_debug_stagger(int(sys.argv[5]))
 for layer in (5,):
-    for mask in (0, 1, 2, 4, 8, 3, 7, 15):
+    for mask in (0, 1, 16, 32, 8, 9, 15):
         ms, tf = run(mask, layer)
         print(f"layer {layer:2d} mask {mask:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s-equivalent", flush=True)
