@@ -352,3 +352,87 @@ def test_bf16_full_chain_close_to_fp32_reference(golden, dev, dh):
     err = rel_err(xp.cpu().numpy(), golden["full/ddpm_n5/x"])
     print("bf16 chain rel err vs fp32 reference:", err)
     assert err < 5e-2
+
+
+# ---- direct C-ABI entry points, chunking, graph capture ---------------------------------------------------------
+def test_c_entry_points_match_python_chains(mini, dh, dev):
+    """ap_purify_ddpm / ap_purify_sde / ap_one_shot_denoise (coefficients computed inside the library from the installed
+    tables) give the same result as the chains the Python classes build with ap_purify_chain."""
+    import types
+    from audiopure_amd import _native as N
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    cfg, net, _ = mini
+    B, L, n, seed = 3, 2500, 3, 7
+    x0 = torch.from_numpy(synth.waveforms(B, L, seed=9)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=n)
+    eng = dw._tables()
+    ws = eng.workspace(B, L, dev)
+    out = torch.empty_like(x0)
+
+    dw.set_noise_source(("philox", seed, 5))
+    ref = dw(x0)
+    N.check(eng.lib.ap_purify_ddpm(eng.ctx, N.ptr(x0), n, 1, None, seed, 5, N.ptr(out), B, L, ws.data_ptr(), ws.numel(),
+                                   N.stream()), "ap_purify_ddpm")
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+
+    ref1 = dw.one_shot_denoise(x0)
+    N.check(eng.lib.ap_one_shot_denoise(eng.ctx, N.ptr(x0), n, N.ptr(out), B, L, ws.data_ptr(), ws.numel(), N.stream()))
+    assert rel_err(out.cpu().numpy(), ref1.cpu().numpy()) < 2e-6
+
+    args = types.SimpleNamespace(t=n, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1)
+    rev = RevDiffWave.from_model(dw, args)
+    eng.set_sde_schedule(rev.rev_vpsde.discrete_betas, rev.rev_vpsde.alphas_cumprod)
+    dw.set_noise_source(("philox", seed, 5))
+    ref2 = rev(x0)
+    N.check(eng.lib.ap_purify_sde(eng.ctx, N.ptr(x0), n, None, seed, 5, N.ptr(out), B, L, ws.data_ptr(), ws.numel(),
+                                  N.stream()), "ap_purify_sde")
+    assert rel_err(out.cpu().numpy(), ref2.cpu().numpy()) < 2e-6
+    # sample_step = 2 concatenates along the batch axis like the reference (diffwave_sde.py:212)
+    args.sample_step = 2
+    assert RevDiffWave.from_model(dw, args)(x0).shape[0] == 2 * B
+
+
+def test_chunked_batches_equal_one_call(mini, dh, dev):
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = mini
+    x0 = torch.from_numpy(synth.waveforms(5, 1000, seed=2)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    dw.set_noise_source(("philox", 3, 0))
+    eng = net.engine()
+    old = eng.max_chunk
+    try:
+        eng.max_chunk = 512
+        a = dw(x0)
+        eng.max_chunk = 2                      # 3 native calls: utt_offset carries the global index
+        b = dw(x0)
+    finally:
+        eng.max_chunk = old
+    assert torch.equal(a, b)
+
+
+def test_purify_is_hip_graph_capturable(mini, dh, dev):
+    """The launch functions never allocate or synchronise (include/audiopure.h): capture a whole purification and replay it."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = mini
+    x0 = torch.from_numpy(synth.waveforms(2, 2000, seed=4)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    dw.set_noise_source(("philox", 11, 0))
+    ref = dw(x0)                               # warm: engine, workspace and output allocations exist
+    static_in = x0.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dw(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        static_out = dw(static_in)
+    static_in.copy_(x0 * 0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, dw(x0 * 0.5))
+    static_in.copy_(x0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref)
