@@ -63,6 +63,12 @@ SIGNATURES = {
     "ap_m5_blob_elems": (_sz, [_i, _i, _i]),
     "ap_m5_fwd": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_melspec_db": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_conv2d_pack": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "ap_conv2d_fwd": (_i, [_fp, _fp, _fp, _fp, _fp] + [_i] * 13 + [_vp]),
+    "ap_affine_nchw": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ap_add_nchw": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ap_copy_channels": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ap_pool2d": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ap_philox_normal": (_i, [_fp, _u64, _u32, _u64, _i, _i, _vp]),
 }
 

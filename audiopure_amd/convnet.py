@@ -1,0 +1,412 @@
+"""Native execution of the reference's 2-D ConvNet classifiers.
+
+The eval scripts receive the classifier as an arbitrary pickled ``nn.Module`` (``audio_models/create_model.py:8-17``):
+VGG19-BN, ResNet, WideResNet, ResNeXt, DPN or DenseNet from ``audio_models/ConvNets_SpeechCommands/models``.  All of
+them are static graphs of conv / batch-norm / ReLU / pooling / add / cat / slice / linear, so instead of one
+hand-written executor per family the module is *lowered once*: an eval-mode forward on a tiny CPU example is recorded
+at the ATen level (``TorchDispatchMode`` — immune to how the Python is written, e.g. ``resnext.py`` calling
+``.forward`` directly), BatchNorm is folded into the preceding conv (or becomes a per-channel affine), ReLU / residual
+adds are fused where the graph allows, and the resulting plan runs on the HIP primitives of ``include/audiopure.h``
+(``ap_conv2d_fwd`` = conv-as-GEMM on the fp32 MFMA, ``ap_affine_nchw``, ``ap_add_nchw``, ``ap_copy_channels``,
+``ap_pool2d``).  PyTorch allocates the buffers; no torch operator runs in ``forward``.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+import torch.nn as nn
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from . import _native as N
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 1. ATen tape
+# ---------------------------------------------------------------------------------------------------------
+class _Tape(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.entries = []
+        self.keep = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        self.entries.append((func, args, kwargs or {}, out))
+        self.keep.append((args, out))
+        return out
+
+
+def _opname(func) -> str:
+    return func._schema.name.split("::")[-1]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 2. plan
+# ---------------------------------------------------------------------------------------------------------
+@dataclass
+class Val:
+    """A [B, C, H, W] activation: channels [coff, coff + C) of buffer `buf`, which has `cstride` channels."""
+    buf: int
+    C: int
+    H: int
+    W: int
+    cstride: int
+    coff: int = 0
+
+    @property
+    def full(self):
+        return self.coff == 0 and self.C == self.cstride
+
+
+@dataclass
+class Step:
+    kind: str                      # conv | affine | add | copy | pool
+    out: Val = None
+    ins: list = field(default_factory=list)
+    p: dict = field(default_factory=dict)
+
+
+class Plan:
+    def __init__(self):
+        self.steps: list[Step] = []
+        self.nbuf = 0
+        self.buf_shape = {}            # buf id -> (C, H, W)
+        self.input: Val = None
+        self.output: Val = None
+        self.weights = {}              # name -> host tensor (folded conv weights / biases / affine vectors)
+
+    def new_buf(self, C, H, W) -> Val:
+        b = self.nbuf
+        self.nbuf += 1
+        self.buf_shape[b] = (C, H, W)
+        return Val(b, C, H, W, C, 0)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
+    """Record one eval forward of `module` on a CPU example [2, C, H, W] and turn it into a Plan."""
+    m = copy.deepcopy(module).to("cpu").float().eval()
+    names = {}
+    for n_, t in list(m.named_parameters()) + list(m.named_buffers()):
+        names[id(t)] = n_
+    x = torch.zeros((2,) + tuple(example_chw))
+    tape = _Tape()
+    with torch.no_grad(), tape:
+        y = m(x)
+    plan = Plan()
+    vals: dict[int, Any] = {}         # id(tensor) -> Val | ("param", tensor) | ("paramT", tensor)
+    plan.input = plan.new_buf(*example_chw)
+    vals[id(x)] = plan.input
+
+    def get(t):
+        if id(t) in vals:
+            return vals[id(t)]
+        if id(t) in names or isinstance(t, nn.Parameter):
+            return ("param", t)
+        raise NotImplementedError("convnet lowering: tensor with unknown producer")
+
+    wcount = [0]
+
+    def add_weight(t):
+        k = f"w{wcount[0]}"
+        wcount[0] += 1
+        plan.weights[k] = t.detach().float().contiguous().clone()
+        return k
+
+    for func, args, kwargs, out in tape.entries:
+        op = _opname(func)
+        if op in ("detach", "alias", "clone", "contiguous", "_to_copy", "dropout", "native_dropout"):
+            src = args[0]
+            vals[id(out if not isinstance(out, tuple) else out[0])] = get(src)
+        elif op == "convolution":
+            xin, w, b, stride, padding, dilation, transposed, _, groups = args[:9]
+            assert not transposed and tuple(dilation) == (1, 1), "dilated / transposed conv2d not lowered"
+            s, p_ = _pair(stride), _pair(padding)
+            assert s[0] == s[1] and p_[0] == p_[1], "anisotropic stride / padding not lowered"
+            v = get(xin)
+            o = plan.new_buf(out.shape[1], out.shape[2], out.shape[3])
+            plan.steps.append(Step("conv", o, [v], dict(w=w.detach().float(), b=None if b is None else b.detach().float(),
+                                                        stride=s[0], pad=p_[0], groups=groups, relu=False, res=None,
+                                                        kh=w.shape[2], kw=w.shape[3])))
+            vals[id(out)] = o
+        elif op in ("_native_batch_norm_legit_no_training", "native_batch_norm", "cudnn_batch_norm",
+                    "_native_batch_norm_legit"):
+            xin, w, b, mean, var = args[:5]
+            eps = args[-1] if op != "cudnn_batch_norm" else args[7]
+            v = get(xin)
+            scale = (w if w is not None else torch.ones_like(mean)).detach().double() / torch.sqrt(var.detach().double() + eps)
+            shift = (b if b is not None else torch.zeros_like(mean)).detach().double() - mean.detach().double() * scale
+            o = plan.new_buf(v.C, v.H, v.W)
+            plan.steps.append(Step("affine", o, [v], dict(scale=scale.float(), shift=shift.float(), relu=False)))
+            vals[id(out[0])] = o
+        elif op in ("relu", "relu_"):
+            v = get(args[0])
+            o = plan.new_buf(v.C, v.H, v.W)
+            plan.steps.append(Step("affine", o, [v], dict(scale=None, shift=None, relu=True)))
+            vals[id(out)] = o                       # relu_ returns its (mutated) input: later uses see the new value
+        elif op in ("add", "add_"):
+            a, b = get(args[0]), get(args[1])
+            assert kwargs.get("alpha", 1) == 1 and isinstance(a, Val) and isinstance(b, Val)
+            assert (a.C, a.H, a.W) == (b.C, b.H, b.W)
+            o = plan.new_buf(a.C, a.H, a.W)
+            plan.steps.append(Step("add", o, [a, b], dict(relu=False)))
+            vals[id(out)] = o
+        elif op == "cat":
+            ts, dim = args[0], (args[1] if len(args) > 1 else 0)
+            assert dim == 1, "only channel concatenation is lowered"
+            vs = [get(t) for t in ts]
+            o = plan.new_buf(sum(v.C for v in vs), vs[0].H, vs[0].W)
+            off = 0
+            for v in vs:
+                plan.steps.append(Step("copy", Val(o.buf, v.C, v.H, v.W, o.cstride, off), [v]))
+                off += v.C
+            vals[id(out)] = o
+        elif op == "slice":
+            xin, dim = args[0], args[1] if len(args) > 1 else 0
+            start = args[2] if len(args) > 2 and args[2] is not None else 0
+            end = args[3] if len(args) > 3 and args[3] is not None else xin.shape[dim]
+            step = args[4] if len(args) > 4 else 1
+            v = get(xin)
+            end = min(end, xin.shape[dim])
+            if dim == 0 or (start == 0 and end >= xin.shape[dim]):
+                vals[id(out)] = v
+            else:
+                assert dim == 1 and step == 1 and isinstance(v, Val), "only channel slices are lowered"
+                vals[id(out)] = Val(v.buf, end - start, v.H, v.W, v.cstride, v.coff + start)
+        elif op in ("max_pool2d_with_indices", "max_pool2d", "avg_pool2d"):
+            xin, k = args[0], _pair(args[1])
+            stride = _pair(args[2]) if len(args) > 2 and args[2] else k
+            pad = _pair(args[3]) if len(args) > 3 else (0, 0)
+            assert k[0] == k[1] and stride[0] == stride[1] and pad[0] == pad[1]
+            if op == "avg_pool2d":
+                assert pad[0] == 0 or (len(args) <= 5 or args[5]), "count_include_pad=False not lowered"
+            v = get(xin)
+            if not v.full:
+                c = plan.new_buf(v.C, v.H, v.W)
+                plan.steps.append(Step("copy", c, [v]))
+                v = c
+            o_t = out[0] if isinstance(out, tuple) else out
+            o = plan.new_buf(v.C, o_t.shape[2], o_t.shape[3])
+            plan.steps.append(Step("pool", o, [v], dict(k=k[0], stride=stride[0], pad=pad[0], is_max=op != "avg_pool2d")))
+            vals[id(o_t)] = o
+        elif op in ("mean", "adaptive_avg_pool2d", "_adaptive_avg_pool2d"):
+            v = get(args[0])
+            if op == "mean":
+                dims = sorted(d % 4 for d in args[1])
+                assert dims == [2, 3], "only spatial means are lowered"
+            else:
+                assert _pair(args[1]) == (1, 1)
+            assert v.H == v.W
+            if not v.full:
+                c = plan.new_buf(v.C, v.H, v.W)
+                plan.steps.append(Step("copy", c, [v]))
+                v = c
+            o = plan.new_buf(v.C, 1, 1)
+            plan.steps.append(Step("pool", o, [v], dict(k=v.H, stride=v.H, pad=0, is_max=False)))
+            vals[id(out)] = o
+        elif op in ("view", "_unsafe_view", "reshape", "flatten", "squeeze", "unsqueeze"):
+            v = get(args[0])
+            if isinstance(v, tuple):
+                vals[id(out)] = v
+                continue
+            n_el = v.C * v.H * v.W
+            assert out.numel() == 2 * n_el, "views that mix the batch axis are not lowered"
+            if not v.full:
+                c = plan.new_buf(v.C, v.H, v.W)
+                plan.steps.append(Step("copy", c, [v]))
+                v = c
+            if out.dim() == 2:
+                vals[id(out)] = Val(v.buf, n_el, 1, 1, n_el, 0)      # [B, C*H*W]: same memory
+            else:
+                vals[id(out)] = Val(v.buf, out.shape[1], out.shape[2], out.shape[3], out.shape[1], 0)
+        elif op == "t":
+            vals[id(out)] = ("paramT", args[0])
+        elif op in ("addmm", "mm", "linear"):
+            if op == "addmm":
+                b, xin, wt = args[0], args[1], args[2]
+                kind, w = get(wt)
+                assert kind == "paramT"
+            elif op == "mm":
+                b, xin = None, args[0]
+                kind, w = get(args[1])
+                assert kind == "paramT"
+            else:
+                xin, w, b = args[0], args[1], (args[2] if len(args) > 2 else None)
+            v = get(xin)
+            assert v.H == 1 and v.W == 1 and v.full
+            o = plan.new_buf(w.shape[0], 1, 1)
+            plan.steps.append(Step("conv", o, [v], dict(w=w.detach().float().reshape(w.shape[0], w.shape[1], 1, 1),
+                                                        b=None if b is None else b.detach().float(), stride=1, pad=0,
+                                                        groups=1, relu=False, res=None, kh=1, kw=1)))
+            vals[id(out)] = o
+        elif op in ("size", "sym_size", "empty", "zeros", "ones", "zeros_like", "empty_like", "fill_", "copy_"):
+            continue
+        else:
+            raise NotImplementedError(f"convnet lowering: ATen op '{op}' is not supported")
+    plan.output = get(y)
+    assert isinstance(plan.output, Val)
+    _fuse(plan)
+    for st in plan.steps:
+        if st.kind == "conv":
+            st.p["wk"] = add_weight(st.p.pop("w"))
+            b = st.p.pop("b")
+            st.p["bk"] = None if b is None else add_weight(b)
+            sc = st.p.pop("scale", None)
+            st.p["sk"] = None if sc is None else add_weight(sc)
+        elif st.kind == "affine" and st.p["scale"] is not None:
+            st.p["sk"], st.p["hk"] = add_weight(st.p.pop("scale")), add_weight(st.p.pop("shift"))
+        elif st.kind == "affine":
+            st.p.pop("scale"), st.p.pop("shift")
+            st.p["sk"] = st.p["hk"] = None
+    return plan
+
+
+def _fuse(plan: Plan):
+    """conv -> BN (fold) -> ReLU, BN -> ReLU, add -> ReLU, conv (+ residual add) peepholes.  A producer is merged into
+    its consumer only when that consumer is the ONLY reader of the producer's buffer."""
+    def readers(buf):
+        r = sum(1 for s in plan.steps for v in s.ins if v.buf == buf)
+        return r + (1 if plan.output.buf == buf else 0)
+
+    changed = True
+    while changed:
+        changed = False
+        for i, st in enumerate(plan.steps):
+            if st.kind not in ("affine", "add"):
+                continue
+            src = st.ins[0]
+            prod = next((s for s in plan.steps[:i] if s.out is not None and s.out.buf == src.buf and s.out.full), None)
+            if st.kind == "affine" and prod is not None and src.full and readers(src.buf) == 1:
+                has_aff = st.p["scale"] is not None
+                if prod.kind == "conv" and not prod.p["relu"] and (prod.p["res"] is None or not has_aff):
+                    if has_aff:        # fold BN: w' = w * s, b' = b * s + t
+                        s_, t_ = st.p["scale"], st.p["shift"]
+                        prod.p["scale"] = s_ if prod.p.get("scale") is None else prod.p["scale"] * s_
+                        b0 = prod.p["b"] if prod.p["b"] is not None else torch.zeros_like(t_)
+                        prod.p["b"] = b0 * s_ + t_
+                    prod.p["relu"] = st.p["relu"]
+                elif prod.kind in ("affine", "add") and not has_aff and not prod.p["relu"]:
+                    prod.p["relu"] = True
+                else:
+                    continue
+                prod.out = st.out
+                plan.steps.pop(i)
+                changed = True
+                break
+            if st.kind == "add" and not st.p["relu"]:
+                # conv + residual: the conv output is read only by this add -> let the conv epilogue add the other operand
+                for a_i in (0, 1):
+                    cv, other = st.ins[a_i], st.ins[1 - a_i]
+                    prod = next((s for s in plan.steps[:i] if s.kind == "conv" and s.out.buf == cv.buf), None)
+                    if (prod is not None and cv.full and other.full and readers(cv.buf) == 1 and not prod.p["relu"]
+                            and prod.p["res"] is None
+                            and all(s2.out.buf != other.buf for s2 in plan.steps[plan.steps.index(prod):i])):
+                        prod.p["res"] = other
+                        prod.ins.append(other)
+                        prod.out = st.out
+                        plan.steps.pop(i)
+                        changed = True
+                        break
+                if changed:
+                    break
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3. executor
+# ---------------------------------------------------------------------------------------------------------
+class NativeConvNet(nn.Module):
+    """``NativeConvNet(module)(x)`` == ``module.eval()(x)`` for the reference's 2-D classifiers, computed by the HIP
+    library.  The wrapped module keeps owning the parameters (``.module``); call ``refresh()`` after changing them."""
+
+    def __init__(self, module: nn.Module, input_chw=(1, 32, 32)):
+        super().__init__()
+        self.module = module
+        self.input_chw = tuple(input_chw)
+        self.plan = lower(module, self.input_chw)
+        self._dev_weights = None
+        self._dev = None
+
+    def _get_name(self):                       # the scripts print / branch on the classifier's class name
+        return self.module._get_name()
+
+    def refresh(self):
+        self.plan = lower(self.module, self.input_chw)
+        self._dev_weights = None
+
+    def _prepare(self, dev):
+        lib = N.lib()
+        W = {k: v.to(dev) for k, v in self.plan.weights.items()}
+        packed = {}
+        for i, st in enumerate(self.plan.steps):
+            if st.kind != "conv":
+                continue
+            w = W[st.p["wk"]]
+            Cout, Cg, kh, kw = w.shape
+            wT = torch.empty(Cout * Cg * kh * kw, device=dev, dtype=torch.float32)
+            sc = W[st.p["sk"]].contiguous() if st.p["sk"] else None
+            N.check(lib.ap_conv2d_pack(N.ptr(w.contiguous()), N.ptr(sc), N.ptr(wT), Cout, Cg, kh, kw, st.p["groups"], N.stream()),
+                    "ap_conv2d_pack")
+            packed[i] = wT
+        torch.cuda.synchronize(dev)
+        self._dev_weights, self._packed, self._dev = W, packed, dev
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("NativeConvNet: inference only (BatchNorm folded); call .eval()")
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("NativeConvNet: forward-only HIP path; autograd through it is not implemented")
+        if x.dim() != 4 or tuple(x.shape[1:]) != self.input_chw:
+            raise ValueError(f"expected [B, {self.input_chw}], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise N.NativeError("NativeConvNet needs a HIP device tensor; there is no CPU path")
+        dev = x.device
+        if self._dev_weights is None or self._dev != dev:
+            self._prepare(dev)
+        lib, W, B, st_ = N.lib(), self._dev_weights, x.shape[0], N.stream()
+        bufs = {self.plan.input.buf: x.detach().float().contiguous()}
+
+        def buf(v):
+            if v.buf not in bufs:
+                C_, H_, W_ = self.plan.buf_shape[v.buf]
+                bufs[v.buf] = torch.empty((B, C_, H_, W_), device=dev, dtype=torch.float32)
+            return bufs[v.buf]
+
+        for i, s in enumerate(self.plan.steps):
+            o, p = s.out, s.p
+            ob = buf(o)
+            if s.kind == "conv":
+                v = s.ins[0]
+                assert o.full
+                res = N.ptr(buf(p["res"])) if p["res"] is not None else None
+                N.check(lib.ap_conv2d_fwd(N.ptr(buf(v)), N.ptr(self._packed[i]), N.ptr(W[p["bk"]]) if p["bk"] else None, res,
+                                          N.ptr(ob), B, v.C, v.H, v.W, o.C, p["kh"], p["kw"], p["stride"], p["pad"],
+                                          p["groups"], int(p["relu"]), v.cstride, v.coff, st_), "ap_conv2d_fwd")
+            elif s.kind == "affine":
+                v = s.ins[0]
+                assert o.full
+                N.check(lib.ap_affine_nchw(N.ptr(buf(v)), N.ptr(W[p["sk"]]) if p["sk"] else None,
+                                           N.ptr(W[p["hk"]]) if p["hk"] else None, N.ptr(ob), B, v.C, v.H * v.W, v.cstride,
+                                           v.coff, int(p["relu"]), st_), "ap_affine_nchw")
+            elif s.kind == "add":
+                a, b = s.ins
+                assert o.full
+                N.check(lib.ap_add_nchw(N.ptr(buf(a)), N.ptr(buf(b)), N.ptr(ob), B, a.C, a.H * a.W, a.cstride, a.coff,
+                                        b.cstride, b.coff, int(p["relu"]), st_), "ap_add_nchw")
+            elif s.kind == "copy":
+                v = s.ins[0]
+                N.check(lib.ap_copy_channels(N.ptr(buf(v)), N.ptr(ob), B, v.C, v.H * v.W, v.cstride, v.coff, o.cstride,
+                                             o.coff, st_), "ap_copy_channels")
+            elif s.kind == "pool":
+                v = s.ins[0]
+                N.check(lib.ap_pool2d(N.ptr(buf(v)), N.ptr(ob), B * v.C, v.H, v.W, p["k"], p["stride"], p["pad"],
+                                      int(p["is_max"]), st_), "ap_pool2d")
+        o = self.plan.output
+        out = buf(o)
+        assert o.full
+        return out.view(B, -1) if (o.H == 1 and o.W == 1) else out

@@ -209,6 +209,34 @@ int ap_m5_fwd(ap_m5 *m, const float *x, float *logprobs, int B, int L, void *str
  * transforms/transforms_stft.py:101-114 (ToSTFT + ToMelSpectrogramFromSTFT). */
 int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L, void *stream);
 
+/* ---- 2-D ConvNet classifiers on the mel front-end (audio_models/ConvNets_SpeechCommands/models/*: vgg.py, resnet.py,
+ * wideresnet.py, resnext.py:67-142, dpn.py, densenet.py).  The host lowers an eval-mode network
+ * to these NCHW fp32 primitives (audiopure_amd/convnet.py); BatchNorm is folded into the conv or applied as a
+ * per-channel affine.  `*_cstride` / `*_coff`: the operand is channels [coff, coff+C) of a tensor with cstride channels
+ * (torch.cat results and x[:, :d] slices are consumed in place).
+ *
+ * ap_conv2d_pack: w [Cout][Cin/g][kh][kw] (times scale[Cout] if non-NULL, the folded BatchNorm gamma/sqrt(var+eps))
+ *   -> wT [groups][ (Cin/g) kh kw ][Cout/g], the A-operand image of the implicit GEMM.
+ * ap_conv2d_fwd: out = [relu]( conv2d(x, w, stride, pad, groups) + bias + res ), nn.Conv2d semantics (cross-correlation,
+ *   zero padding); bias / res may be NULL; res has the shape of out.  conv-as-GEMM on v_mfma_f32_32x32x2_f32.
+ *   nn.Linear is the kh = kw = H = W = 1 case. */
+int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw, int groups,
+                   void *stream);
+int ap_conv2d_fwd(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin,
+                  int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride,
+                  int x_coff, void *stream);
+/* y[B][C][HW] = [relu](x * scale[c] + shift[c]); scale == NULL: plain (optionally ReLU'd) copy of the slice. */
+int ap_affine_nchw(const float *x, const float *scale, const float *shift, float *y, int B, int C, int HW,
+                   int x_cstride, int x_coff, int relu, void *stream);
+/* y = [relu](a + b) on channel slices. */
+int ap_add_nchw(const float *a, const float *b, float *y, int B, int C, int HW, int a_cstride, int a_coff,
+                int b_cstride, int b_coff, int relu, void *stream);
+/* dst[:, d_coff : d_coff + C] = src[:, s_coff : s_coff + C]  (torch.cat). */
+int ap_copy_channels(const float *src, float *dst, int B, int C, int HW, int s_cstride, int s_coff, int d_cstride,
+                     int d_coff, void *stream);
+/* nn.MaxPool2d / F.avg_pool2d(k, stride, pad) on [BC][H][W]. */
+int ap_pool2d(const float *x, float *y, int BC, int H, int W, int k, int stride, int pad, int is_max, void *stream);
+
 /* Fill out[B][L] with the library's Philox N(0,1) stream (same values the fused paths use). */
 int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                      void *stream);

@@ -1,0 +1,99 @@
+"""Lowering of the 2-D ConvNet classifiers (ATen tape -> fused plan) checked on CPU: the plan, interpreted with plain
+torch ops, must reproduce the original module.  Structures mirror the reference's families
+(audio_models/ConvNets_SpeechCommands/models/{vgg,resnext,wideresnet,densenet,dpn}.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init, vgg19_bn
+from audiopure_amd.convnet import lower
+from audiopure_amd import synth
+from oracle.convnet_plan_oracle import run_plan_torch
+
+
+class PreActBlock(nn.Module):      # wideresnet.py:30-39 (BN-ReLU before conv, conv shortcut when shapes change)
+    def __init__(s, cin, cout, stride):
+        super().__init__()
+        s.bn1, s.conv1 = nn.BatchNorm2d(cin), nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        s.bn2, s.conv2 = nn.BatchNorm2d(cout), nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        s.equal = cin == cout
+        s.short = None if s.equal else nn.Conv2d(cin, cout, 1, stride, 0, bias=False)
+
+    def forward(s, x):
+        if not s.equal:
+            x = F.relu(s.bn1(x))
+            out = x
+        else:
+            out = F.relu(s.bn1(x))
+        out = s.conv2(F.relu(s.bn2(s.conv1(out))))
+        return torch.add(x if s.equal else s.short(x), out)
+
+
+class DenseDPN(nn.Module):         # densenet.py:29-41 (cat) + dpn.py:36-44 (slices, partial add, cat)
+    def __init__(s):
+        super().__init__()
+        s.conv0 = nn.Conv2d(1, 16, 3, 1, 1, bias=False)
+        s.bn1, s.c1 = nn.BatchNorm2d(16), nn.Conv2d(16, 12, 1, bias=False)
+        s.bn2, s.c2 = nn.BatchNorm2d(28), nn.Conv2d(28, 28, 3, 1, 1, groups=4, bias=False)
+        s.bn3 = nn.BatchNorm2d(28)
+        s.pre = PreActBlock(36, 48, 2)
+        s.pre2 = PreActBlock(48, 48, 1)
+        s.fc = nn.Linear(48, 7)
+
+    def forward(s, x):
+        x = s.conv0(x)
+        x = torch.cat((x, s.c1(F.relu(s.bn1(x)))), 1)                       # 28 ch
+        out = s.bn3(s.c2(F.relu(s.bn2(x))))
+        d = 20
+        x = torch.cat([x[:, :d, :, :] + out[:, :d, :, :], x[:, d:, :, :], out[:, d:, :, :]], 1)   # 36 ch
+        x = F.relu(x)
+        x = s.pre2(s.pre(x))
+        x = F.avg_pool2d(x, 16)
+        return s.fc(x.view(x.size(0), -1))
+
+
+def _x(B=3):
+    return torch.from_numpy(synth.uniform("mel", (B, 1, 32, 32), 3, -2.0, 2.0))
+
+
+@pytest.mark.parametrize("make", [lambda: vgg19_bn(10, 1, width_div=8), lambda: CifarResNeXt(10, cardinality=4, base_width=8),
+                                  DenseDPN])
+def test_plan_reproduces_module(make):
+    m = synth_init(make(), 1)
+    plan = lower(m)
+    x = _x()
+    with torch.no_grad():
+        ref = m(x)
+    got = run_plan_torch(plan, x)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+    kinds = [s.kind for s in plan.steps]
+    assert "conv" in kinds
+
+
+def test_fusions_happen():
+    plan = lower(synth_init(vgg19_bn(10, 1, width_div=8), 1))
+    kinds = [s.kind for s in plan.steps]
+    assert kinds.count("conv") == 16 + 3 and kinds.count("affine") == 0 and kinds.count("pool") == 5   # BN+ReLU folded
+    plan = lower(synth_init(CifarResNeXt(10, cardinality=4, base_width=8), 1))
+    convs = [s for s in plan.steps if s.kind == "conv"]
+    assert len(convs) == 1 + 9 * 3 + 3 + 1 and sum(1 for s in convs if s.p["res"] is not None) == 9     # residuals fused
+    assert not any(s.kind in ("add", "affine") for s in plan.steps)
+
+
+def test_unsupported_graph_is_loud():
+    class Bad(nn.Module):
+        def forward(s, x):
+            return torch.sigmoid(x).mean((2, 3))
+    with pytest.raises(NotImplementedError):
+        lower(Bad())
+
+
+def test_restated_models_have_reference_state_dict_keys():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_convnets_v1.npz"))
+    assert list(vgg19_bn(10, 1).state_dict().keys()) == list(g["vgg19_bn/keys"])
+    assert list(CifarResNeXt(10).state_dict().keys()) == list(g["resnext29_8_64/keys"])
+    assert sum(p.numel() for p in CifarResNeXt(10).parameters()) == 34425546

@@ -1,0 +1,100 @@
+"""GPU parity of the lowered 2-D ConvNet classifiers: HIP conv-as-GEMM executor vs the
+PyTorch-CPU module (the oracle for an arbitrary classifier is the module itself) and vs logits produced by the
+REFERENCE's own model classes (tests/golden/golden_convnets_v1.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiopure_amd import synth
+from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init, vgg19_bn
+from audiopure_amd.convnet import NativeConvNet
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5          # exact fp32 products, different summation order, through up to ~50 layers
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_convnets_v1.npz"))
+
+
+def _x(B=2):
+    return torch.from_numpy(synth.uniform("mel", (B, 1, 32, 32), 3, -2.0, 2.0))
+
+
+@pytest.mark.parametrize("name,make", [("vgg19_bn", lambda: vgg19_bn(10, 1)), ("resnext29_8_64", lambda: CifarResNeXt(10))])
+def test_full_models_match_reference_golden(dev, gold, name, make):
+    m = synth_init(make(), 0)
+    net = NativeConvNet(m).eval()
+    y = net(_x().to(dev)).cpu().numpy()
+    assert y.shape == (2, 10)
+    assert rel_err(y, gold[f"{name}/logits"]) < TOL
+    assert net._get_name() == type(m).__name__
+    # batch-size independence of the plan + row independence (FAKEBOB reshapes scores per sample, _utils.py:118-119)
+    y5 = net(_x(5).to(dev)).cpu().numpy()
+    with torch.no_grad():
+        ref5 = m(_x(5)).numpy()
+    assert rel_err(y5, ref5) < TOL
+
+
+def test_family_structures_match_module(dev):
+    from test_convnet_lowering_cpu import DenseDPN
+    m = synth_init(DenseDPN(), 2)
+    x = _x(7)
+    with torch.no_grad():
+        ref = m(x).numpy()
+    assert rel_err(NativeConvNet(m).eval()(x.to(dev)).cpu().numpy(), ref) < TOL
+
+
+def test_conv2d_primitive_edge_shapes(dev):
+    """ap_conv2d_fwd alone: grouped, strided, 1x1, Cout not a multiple of the tile, N not a multiple of the tile."""
+    import torch.nn.functional as F
+    from audiopure_amd import _native as N
+    lib = N.lib()
+    for (B, Cin, H, Cout, k, s, p, g) in [(3, 8, 9, 12, 3, 1, 1, 1), (2, 16, 16, 40, 3, 2, 1, 4), (5, 33, 7, 70, 1, 1, 0, 1),
+                                          (1, 64, 4, 64, 3, 1, 1, 8), (4, 1, 32, 64, 3, 1, 1, 1)]:
+        x = torch.from_numpy(synth.uniform(f"cx{Cin}{H}", (B, Cin, H, H), 1))
+        w = torch.from_numpy(synth.uniform(f"cw{Cin}{Cout}", (Cout, Cin // g, k, k), 1))
+        b = torch.from_numpy(synth.uniform(f"cb{Cout}", (Cout,), 1))
+        ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p, groups=g))
+        xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+        wT = torch.empty(w.numel(), device=dev)
+        N.check(lib.ap_conv2d_pack(N.ptr(wd), None, N.ptr(wT), Cout, Cin // g, k, k, g, N.stream()))
+        out = torch.empty(ref.shape, device=dev)
+        N.check(lib.ap_conv2d_fwd(N.ptr(xd), N.ptr(wT), N.ptr(bd), None, N.ptr(out), B, Cin, H, H, Cout, k, k, s, p, g, 1,
+                                  Cin, 0, N.stream()))
+        assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6, (B, Cin, H, Cout, k, s, p, g)
+
+
+def test_mel_classifier_pipeline_end_to_end(dev):
+    """AcousticSystem(classifier=ResNeXt, transform=mel-dB, defender=DiffWave) fully on the HIP path
+    (the eval scripts' default wave-defense + spectrogram-classifier setup, adaptive_attack_eval.py:83-137)."""
+    from audiopure_amd.acoustic_system import AcousticSystem
+    from audiopure_amd.transforms import MelSpecDB
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from oracle import diffwave_oracle as O
+    cfg = synth.mini_wavenet_config(64, 12, 12)
+    sd = synth.wavenet_state_dict(cfg, 0)
+    wn = WaveNet_Speech_Commands(**cfg)
+    wn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    dw = DiffWave(wn.to(dev), calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG), reverse_timestep=2)
+    z = [torch.from_numpy(synth.noise(d, 2, 16000, seed=11)) for d in range(2)]
+    dw.set_noise_source(list(z))
+    clf = synth_init(CifarResNeXt(10, cardinality=4, base_width=8), 1)
+    system = AcousticSystem(classifier=NativeConvNet(clf).eval(), transform=MelSpecDB(32), defender=dw, defense_type="wave")
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=11))
+    logits = system(x0.to(dev), True).cpu()
+    xp = O.ddpm_purify(O.fold_state_dict(sd), cfg, O.diffusion_hyperparams(**synth.DIFFUSION_CONFIG), x0, 2, z)
+    with torch.no_grad():
+        ref = clf(O.melspec_db(xp))
+    assert rel_err(logits.numpy(), ref.numpy()) < 5e-3        # mel dB amplifies tiny spectral differences
