@@ -69,6 +69,12 @@ SIGNATURES = {
     "ap_add_nchw": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ap_copy_channels": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ap_pool2d": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ap_groupnorm_nchw": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ap_timestep_embedding": (_i, [_fp, _fp, _fp, _i, _i, _vp]),
+    "ap_silu": (_i, [_fp, _fp, _sz, _vp]),
+    "ap_upsample_nearest2x": (_i, [_fp, _fp, _i, _i, _i, _vp]),
+    "ap_attention_qkv": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_axpbyc": (_i, [_fp, _fp, _fp, _f, _f, _f, _sz, _vp]),
     "ap_philox_normal": (_i, [_fp, _u64, _u32, _u64, _i, _i, _vp]),
 }
 

@@ -262,3 +262,202 @@ extern "C" int ap_pool2d(const float *x, float *y, int BC, int H, int W, int k, 
   AP_HIP(hipGetLastError());
   return 0;
 }
+
+// =============================================================================================================
+// Improved-Diffusion UNet pieces (improved_diffusion/unet.py, nn.py)
+// =============================================================================================================
+namespace ap {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// GroupNorm32 (nn.py:17-19,95-102) [+ (1 + scale) * . + shift of use_scale_shift_norm (unet.py:184-190)] [+ SiLU].
+// One workgroup per (sample, group); two passes (mean, then centred variance) like ATen's RowwiseMoments.
+__global__ __launch_bounds__(256) void groupnorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, const float *__restrict__ ss,
+                                                        float *__restrict__ y, int C, int HW, int groups, float eps,
+                                                        int act) {
+  __shared__ float red[256];
+  const int b = blockIdx.x / groups, g = blockIdx.x % groups, cpg = C / groups, n = cpg * HW;
+  const float *xp = x + ((size_t)b * C + (size_t)g * cpg) * HW;
+  float *yp = y + ((size_t)b * C + (size_t)g * cpg) * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += xp[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float mean = red[0] / (float)n;
+  __syncthreads();
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float dlt = xp[i] - mean;
+    v = __builtin_fmaf(dlt, dlt, v);
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float rstd = 1.0f / sqrtf(red[0] / (float)n + eps);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = g * cpg + i / HW;
+    float o = (xp[i] - mean) * rstd * gamma[c] + beta[c];
+    if (ss) o = o * (1.0f + ss[(size_t)b * 2 * C + c]) + ss[(size_t)b * 2 * C + C + c];
+    if (act == 2) o = silu_f(o);
+    else if (act == 1) o = fmaxf(o, 0.f);
+    yp[i] = o;
+  }
+}
+
+// timestep_embedding (nn.py:103-121): out[b] = [cos(t_b f_j), sin(t_b f_j)]
+__global__ void timestep_embedding_kernel(const float *__restrict__ t, const float *__restrict__ freqs,
+                                          float *__restrict__ out, int half, int total) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int b = idx / half, jx = idx % half;
+  const float a = t[b] * freqs[jx];
+  out[(size_t)b * 2 * half + jx] = cosf(a);
+  out[(size_t)b * 2 * half + half + jx] = sinf(a);
+}
+
+__global__ void silu_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = silu_f(x[i]);
+}
+
+// F.interpolate(scale_factor=2, mode="nearest") (unet.py:60-72)
+__global__ void upsample2x_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, size_t total) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int W2 = 2 * W, H2 = 2 * H;
+  const int ox = idx % W2;
+  size_t rest = idx / W2;
+  const int oy = rest % H2;
+  const size_t bc = rest / H2;
+  y[idx] = x[(bc * H + (oy >> 1)) * W + (ox >> 1)];
+}
+
+// QKVAttention (unet.py:239-252) on the legacy layout qkv [B][heads][3 ch][T]: one workgroup per (sample, head), K and V
+// of the head in LDS (broadcast reads), one query per thread, exact two-pass softmax in fp32.
+template <int CH>
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ qkv, float *__restrict__ out, int T,
+                                                        int heads, float scale2) {
+  extern __shared__ float sm[];
+  float *ks = sm, *vs = sm + (size_t)CH * T;
+  const int bh = blockIdx.x;
+  const float *base = qkv + (size_t)bh * 3 * CH * T;
+  for (int i = threadIdx.x; i < CH * T; i += 256) {
+    ks[i] = base[(size_t)CH * T + i];
+    vs[i] = base[(size_t)2 * CH * T + i];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 256) {
+    float q[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) q[c] = base[(size_t)c * T + t];
+    float mx = -INFINITY;
+    for (int s = 0; s < T; s++) {
+      float w = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; c++) w = __builtin_fmaf(q[c], ks[c * T + s], w);
+      mx = fmaxf(mx, w * scale2);
+    }
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc[c] = 0.f;
+    float l = 0.f;
+    for (int s = 0; s < T; s++) {
+      float w = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; c++) w = __builtin_fmaf(q[c], ks[c * T + s], w);
+      const float p = expf(w * scale2 - mx);
+      l += p;
+#pragma unroll
+      for (int c = 0; c < CH; c++) acc[c] = __builtin_fmaf(p, vs[c * T + s], acc[c]);
+    }
+    const float inv = 1.0f / l;
+    float *op = out + (size_t)bh * CH * T;
+#pragma unroll
+    for (int c = 0; c < CH; c++) op[(size_t)c * T + t] = acc[c] * inv;
+  }
+}
+
+}  // namespace ap
+
+extern "C" int ap_groupnorm_nchw(const float *x, const float *gamma, const float *beta, const float *scale_shift, float *y,
+                                 int B, int C, int HW, int groups, float eps, int act, void *stream) {
+  if (!x || !gamma || !beta || !y || B < 1 || C < 1 || HW < 1 || groups < 1 || C % groups) { set_error("ap_groupnorm_nchw: bad argument"); return -22; }
+  groupnorm_kernel<<<(unsigned)(B * groups), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, scale_shift, y, C, HW, groups, eps, act);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ap_timestep_embedding(const float *t_dev, const float *freqs_dev, float *out, int B, int dim, void *stream) {
+  if (!t_dev || !freqs_dev || !out || B < 1 || dim < 2 || dim % 2) { set_error("ap_timestep_embedding: bad argument (even dim only)"); return -22; }
+  const int total = B * (dim / 2);
+  timestep_embedding_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(t_dev, freqs_dev, out, dim / 2, total);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ap_silu(const float *x, float *y, size_t n, void *stream) {
+  if (!x || !y || n < 1) { set_error("ap_silu: bad argument"); return -22; }
+  silu_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, n);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ap_upsample_nearest2x(const float *x, float *y, int BC, int H, int W, void *stream) {
+  if (!x || !y || BC < 1 || H < 1 || W < 1) { set_error("ap_upsample_nearest2x: bad argument"); return -22; }
+  size_t total = (size_t)BC * 4 * H * W;
+  upsample2x_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, H, W, total);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ap_attention_qkv(const float *qkv, float *out, int B, int C, int T, int heads, void *stream) {
+  if (!qkv || !out || B < 1 || C < 1 || T < 1 || heads < 1 || C % heads) { set_error("ap_attention_qkv: bad argument"); return -22; }
+  const int ch = C / heads;
+  const size_t smem = (size_t)2 * ch * T * sizeof(float);
+  if (smem > 160 * 1024) { set_error("ap_attention_qkv: K/V of one head (%zu bytes) exceed the LDS", smem); return -22; }
+  const float scale2 = 1.0f / sqrtf((float)ch);          // (1/sqrt(sqrt(ch)))^2, unet.py:247-249
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(B * heads);
+#define AP_ATT(CHV)                                                                                                  \
+  do {                                                                                                               \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      AP_HIP(hipFuncSetAttribute((const void *)attention_kernel<CHV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    attention_kernel<CHV><<<grid, 256, smem, st>>>(qkv, out, T, heads, scale2);                                      \
+  } while (0)
+  switch (ch) {
+    case 8: AP_ATT(8); break;
+    case 16: AP_ATT(16); break;
+    case 32: AP_ATT(32); break;
+    case 64: AP_ATT(64); break;
+    default: set_error("ap_attention_qkv: channels per head %d not built (8, 16, 32, 64)", ch); return -22;
+  }
+#undef AP_ATT
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace ap {
+__global__ void axpbyc_kernel(const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out, float a,
+                              float b, float c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.f) + c;
+}
+}  // namespace ap
+
+extern "C" int ap_axpbyc(const float *x, const float *y, float *out, float a, float b, float c, size_t n, void *stream) {
+  if (!x || !out || n < 1) { set_error("ap_axpbyc: bad argument"); return -22; }
+  ap::axpbyc_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, out, a, b, c, n);
+  AP_HIP(hipGetLastError());
+  return 0;
+}

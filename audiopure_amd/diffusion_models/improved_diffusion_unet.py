@@ -1,0 +1,225 @@
+"""Improved-Diffusion ``UNetModel`` (the spectrogram epsilon-network of the ``DiffSpec`` defense) with the reference's
+constructor, state-dict keys and ``forward(x, timesteps)`` contract
+(diffusion_models/Improved_Diffusion_Unconditional/improved_diffusion/unet.py:278-491, nn.py, script_util.py:15-35,
+99-126), executed on the HIP primitives of include/audiopure.h: conv-as-GEMM on the fp32 MFMA (3x3 / 1x1 / strided),
+GroupNorm32 fused with the scale-shift FiLM and SiLU, QKV attention, nearest up-sampling.
+
+The modules below only HOLD parameters under the reference's names (``input_blocks.4.0.in_layers.2.weight`` ...), so a
+reference checkpoint (``model*.pt`` / ``ema_*.pt`` bare state dicts, train_util.py:274-297) loads unchanged.
+Not built (raises): class conditioning, ``use_scale_shift_norm=False``, ``conv_resample=False``, dims != 2.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+
+
+# ---- parameter holders with the reference's attribute tree -----------------------------------------------------
+class ResBlock(nn.Module):
+    def __init__(self, channels, emb_channels, out_channels):
+        super().__init__()
+        self.channels, self.out_channels = channels, out_channels
+        self.in_layers = nn.Sequential(nn.GroupNorm(32, channels), nn.SiLU(), nn.Conv2d(channels, out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, 2 * out_channels))
+        self.out_layers = nn.Sequential(nn.GroupNorm(32, out_channels), nn.SiLU(), nn.Dropout(0.0),
+                                        nn.Conv2d(out_channels, out_channels, 3, padding=1))
+        self.skip_connection = nn.Identity() if out_channels == channels else nn.Conv2d(channels, out_channels, 1)
+
+
+class AttentionBlock(nn.Module):
+    def __init__(self, channels, num_heads):
+        super().__init__()
+        self.channels, self.num_heads = channels, num_heads
+        self.norm = nn.GroupNorm(32, channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = nn.Conv1d(channels, channels, 1)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.op = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+
+class UNetModel(nn.Module):
+    def __init__(self, in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
+                 attention_resolutions=(2, 4), dropout=0, channel_mult=(1, 2, 2, 2), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, num_heads=4, num_heads_upsample=-1,
+                 use_scale_shift_norm=True):
+        super().__init__()
+        if num_classes is not None or not use_scale_shift_norm or not conv_resample or dims != 2:
+            raise NotImplementedError("audiopure_amd UNetModel: only the unconditional 2-D scale-shift-norm conv-resample "
+                                      "configuration of script_util.py:15-35 is built")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_heads, self.num_heads_upsample = num_heads, num_heads_upsample
+        ted = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.input_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        chans, ch, ds = [model_channels], model_channels, 1
+        for level, mult in enumerate(channel_mult):                       # unet.py:351-380
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, ted, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads))
+                self.input_blocks.append(nn.Sequential(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(nn.Sequential(Downsample(ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = nn.Sequential(ResBlock(ch, ted, ch), AttentionBlock(ch, num_heads), ResBlock(ch, ted, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:           # unet.py:401-430
+            for i in range(num_res_blocks + 1):
+                layers = [ResBlock(ch + chans.pop(), ted, model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(AttentionBlock(ch, num_heads_upsample))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch))
+                    ds //= 2
+                self.output_blocks.append(nn.Sequential(*layers))
+        self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        self._packed, self._key = None, None
+        half = model_channels // 2                                        # nn.py:113-116, as the reference computes them
+        self.register_buffer("_freqs", torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half),
+                             persistent=False)
+
+    # ---- native execution --------------------------------------------------------------------------------------
+    def _prepare(self):
+        ps = list(self.parameters())
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise N.NativeError("audiopure_amd UNetModel needs its parameters on a HIP device (.cuda()); no CPU path")
+        key = (dev, tuple((p._version, p.data_ptr()) for p in ps))
+        if key == self._key:
+            return
+        lib, packed = N.lib(), {}
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Conv1d, nn.Linear)):
+                w = m.weight.detach().float().contiguous()
+                cout = w.shape[0]
+                cin_g = w.shape[1]
+                kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+                wT = torch.empty(w.numel(), device=dev, dtype=torch.float32)
+                N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), cout, cin_g, kh, kw, 1, N.stream()), "ap_conv2d_pack")
+                packed[m] = (wT, m.bias.detach().float().contiguous() if m.bias is not None else None, cout, kh, kw,
+                             (m.stride[0] if hasattr(m, "stride") else 1), (m.padding[0] if hasattr(m, "padding") else 0))
+        torch.cuda.synchronize(dev)
+        self._packed, self._key = packed, key
+
+    def _conv(self, m, x, B, Cin, H, W, res=None):
+        wT, bias, cout, kh, kw, stride, pad = self._packed[m]
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        out = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
+        N.check(N.lib().ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, H, W, cout, kh, kw, stride,
+                                      pad, 1, 0, Cin, 0, N.stream()), "ap_conv2d_fwd")
+        return out
+
+    def _gn(self, gn, x, ss=None, act=2):
+        B, C_, H, W = x.shape
+        y = torch.empty_like(x)
+        N.check(N.lib().ap_groupnorm_nchw(N.ptr(x), N.ptr(gn.weight.detach()), N.ptr(gn.bias.detach()), N.ptr(ss), N.ptr(y), B, C_,
+                                          H * W, gn.num_groups, float(gn.eps), act, N.stream()), "ap_groupnorm_nchw")
+        return y
+
+    def _resblock(self, rb, x, emb_silu):
+        B, C_, H, W = x.shape
+        h = self._conv(rb.in_layers[2], self._gn(rb.in_layers[0], x), B, C_, H, W)                 # unet.py:181
+        ss = self._conv(rb.emb_layers[1], emb_silu, B, emb_silu.shape[1], 1, 1).view(B, -1)        # :182 (SiLU applied once)
+        h = self._gn(rb.out_layers[0], h, ss=ss)                                                   # :186-190 (+ SiLU)
+        skip = x if isinstance(rb.skip_connection, nn.Identity) else self._conv(rb.skip_connection, x, B, C_, H, W)
+        return self._conv(rb.out_layers[3], h, B, rb.out_channels, H, W, res=skip)                 # :194
+
+    def _attention(self, ab, x):
+        B, C_, H, W = x.shape
+        qkv = self._conv(ab.qkv, self._gn(ab.norm, x, act=0), B, C_, H, W)                         # unet.py:229-230
+        att = torch.empty_like(x)
+        N.check(N.lib().ap_attention_qkv(N.ptr(qkv), N.ptr(att), B, C_, H * W, ab.num_heads, N.stream()), "ap_attention_qkv")
+        return self._conv(ab.proj_out, att, B, C_, H, W, res=x)                                    # :234-235
+
+    def _run(self, seq, h, emb_silu):
+        for layer in seq:
+            B, C_, H, W = h.shape
+            if isinstance(layer, ResBlock):
+                h = self._resblock(layer, h, emb_silu)
+            elif isinstance(layer, AttentionBlock):
+                h = self._attention(layer, h)
+            elif isinstance(layer, Downsample):
+                h = self._conv(layer.op, h, B, C_, H, W)
+            elif isinstance(layer, Upsample):
+                up = torch.empty((B, C_, 2 * H, 2 * W), device=h.device, dtype=torch.float32)
+                N.check(N.lib().ap_upsample_nearest2x(N.ptr(h), N.ptr(up), B * C_, H, W, N.stream()), "ap_upsample_nearest2x")
+                h = self._conv(layer.conv, up, B, C_, 2 * H, 2 * W)
+            elif isinstance(layer, nn.Conv2d):
+                h = self._conv(layer, h, B, C_, H, W)
+            else:
+                raise NotImplementedError(type(layer).__name__)
+        return h
+
+    def forward(self, x, timesteps, y=None):
+        assert y is None, "class conditioning is not built"
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("audiopure_amd UNetModel: forward-only HIP path; autograd through it is not implemented")
+        self._prepare()
+        lib = N.lib()
+        x = x.detach().float().contiguous()
+        B, dev = x.shape[0], x.device
+        t = timesteps.detach().to(dev).float().reshape(-1).contiguous()
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B).contiguous()
+        temb = torch.empty((B, self.model_channels), device=dev, dtype=torch.float32)
+        N.check(lib.ap_timestep_embedding(N.ptr(t), N.ptr(self._freqs), N.ptr(temb), B, self.model_channels, N.stream()))
+        e = self._conv(self.time_embed[0], temb, B, self.model_channels, 1, 1).view(B, -1)
+        e_s = torch.empty_like(e)
+        N.check(lib.ap_silu(N.ptr(e), N.ptr(e_s), e.numel(), N.stream()))
+        emb = self._conv(self.time_embed[2], e_s, B, e.shape[1], 1, 1).view(B, -1)                 # unet.py:479
+        emb_silu = torch.empty_like(emb)                                   # every ResBlock starts emb_layers with SiLU
+        N.check(lib.ap_silu(N.ptr(emb), N.ptr(emb_silu), emb.numel(), N.stream()))
+        hs, h = [], x
+        for blk in self.input_blocks:                                       # :486-488
+            h = self._run(blk, h, emb_silu)
+            hs.append(h)
+        h = self._run(self.middle_block, h, emb_silu)
+        for blk in self.output_blocks:                                      # :490-492
+            skip = hs.pop()
+            Bc, C1, H, W = h.shape
+            C2 = skip.shape[1]
+            cat = torch.empty((Bc, C1 + C2, H, W), device=dev, dtype=torch.float32)
+            N.check(lib.ap_copy_channels(N.ptr(h), N.ptr(cat), Bc, C1, H * W, C1, 0, C1 + C2, 0, N.stream()))
+            N.check(lib.ap_copy_channels(N.ptr(skip), N.ptr(cat), Bc, C2, H * W, C2, 0, C1 + C2, C1, N.stream()))
+            h = self._run(blk, cat, emb_silu)
+        Bc, C_, H, W = h.shape
+        return self._conv(self.out[2], self._gn(self.out[0], h), Bc, C_, H, W)                     # :494
+
+
+def model_and_diffusion_defaults():
+    """script_util.py:15-35 (model part)."""
+    return dict(image_size=32, num_channels=128, num_res_blocks=3, num_heads=4, num_heads_upsample=-1,
+                attention_resolutions="16,8", dropout=0.3, learn_sigma=False, class_cond=False, diffusion_steps=200,
+                noise_schedule="linear", use_checkpoint=False, use_scale_shift_norm=True)
+
+
+def create_model(image_size=32, num_channels=128, num_res_blocks=3, learn_sigma=False, class_cond=False,
+                 use_checkpoint=False, attention_resolutions="16,8", num_heads=4, num_heads_upsample=-1,
+                 use_scale_shift_norm=True, dropout=0.3, **_):
+    """script_util.py:86-126."""
+    channel_mult = {256: (1, 1, 2, 2, 4, 4), 64: (1, 2, 3, 4), 32: (1, 2, 2, 2)}[image_size]
+    attention_ds = tuple(image_size // int(r) for r in attention_resolutions.split(","))
+    return UNetModel(in_channels=1, model_channels=num_channels, out_channels=(1 if not learn_sigma else 2),
+                     num_res_blocks=num_res_blocks, attention_resolutions=attention_ds, dropout=dropout,
+                     channel_mult=channel_mult, num_classes=(1000 if class_cond else None), use_checkpoint=use_checkpoint,
+                     num_heads=num_heads, num_heads_upsample=num_heads_upsample, use_scale_shift_norm=use_scale_shift_norm)

@@ -237,6 +237,23 @@ int ap_copy_channels(const float *src, float *dst, int B, int C, int HW, int s_c
 /* nn.MaxPool2d / F.avg_pool2d(k, stride, pad) on [BC][H][W]. */
 int ap_pool2d(const float *x, float *y, int BC, int H, int W, int k, int stride, int pad, int is_max, void *stream);
 
+/* ---- Improved-Diffusion UNet pieces (Improved_Diffusion_Unconditional/improved_diffusion/unet.py, nn.py; section 8 a15).
+ * ap_groupnorm_nchw: GroupNorm32 (nn.py:17-19,95-102) on [B][C][HW], optionally followed by the scale-shift FiLM of
+ *   use_scale_shift_norm, y = gn(x) * (1 + scale[b][c]) + shift[b][c] with scale_shift = [B][2C] (unet.py:184-190),
+ *   and an activation (act: 0 none, 1 ReLU, 2 SiLU).
+ * ap_timestep_embedding: [cos(t f_j), sin(t f_j)] (nn.py:103-121); freqs computed by the host like the reference.
+ * ap_silu, ap_upsample_nearest2x (unet.py:60-72).
+ * ap_attention_qkv: QKVAttention (unet.py:239-252) on qkv [B][heads][3*ch][T] -> [B][heads*ch][T], fp32 softmax. */
+int ap_groupnorm_nchw(const float *x, const float *gamma, const float *beta, const float *scale_shift, float *y, int B,
+                      int C, int HW, int groups, float eps, int act, void *stream);
+int ap_timestep_embedding(const float *t_dev, const float *freqs_dev, float *out, int B, int dim, void *stream);
+int ap_silu(const float *x, float *y, size_t n, void *stream);
+int ap_upsample_nearest2x(const float *x, float *y, int BC, int H, int W, void *stream);
+int ap_attention_qkv(const float *qkv, float *out, int B, int C, int T, int heads, void *stream);
+/* out = a*x + b*y + c elementwise (y may be NULL): melspec_standardize / inv (sc09_spectrogram_dataset.py:65-81) and the
+ * Euler links of the spectrogram SDE (improved_diffusion_sde.py:173-221). */
+int ap_axpbyc(const float *x, const float *y, float *out, float a, float b, float c, size_t n, void *stream);
+
 /* Fill out[B][L] with the library's Philox N(0,1) stream (same values the fused paths use). */
 int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                      void *stream);

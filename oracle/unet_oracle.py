@@ -1,0 +1,130 @@
+"""ORACLE — test infrastructure only.  PyTorch-CPU restatement of the Improved-Diffusion UNet forward
+(improved_diffusion/unet.py:462-491 and the blocks it calls) and of the continuous-beta VP-SDE Euler chain of
+``RevImprovedDiffusion`` (diffusion_models/improved_diffusion_sde.py:48-137,173-221).  It walks a parameter-holder
+``UNetModel`` (same attribute tree / state-dict keys as the reference) with plain torch ops.
+Pinned by tests/test_unet_oracle_golden.py against outputs of the reference's own UNetModel / RevVPSDE
+(tests/golden/make_golden_unet.py).  The torchsde Euler loop itself is restated (parity unpinned, as for DiffWave)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def timestep_embedding(t, dim, max_period=10000):                     # nn.py:103-121
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def _gn(gn, x):
+    return F.group_norm(x.float(), gn.num_groups, gn.weight, gn.bias, gn.eps)      # GroupNorm32, nn.py:17-19
+
+
+def _silu(x):
+    return x * torch.sigmoid(x)                                        # nn.py:12-14
+
+
+def _resblock(rb, x, emb):                                             # unet.py:180-194
+    h = rb.in_layers[2](_silu(_gn(rb.in_layers[0], x)))
+    emb_out = rb.emb_layers[1](_silu(emb))[..., None, None]
+    scale, shift = torch.chunk(emb_out, 2, dim=1)
+    h = _gn(rb.out_layers[0], h) * (1 + scale) + shift
+    h = rb.out_layers[3](_silu(h))
+    return rb.skip_connection(x) + h
+
+
+def _attention(ab, x):                                                 # unet.py:226-252
+    b, c, *spatial = x.shape
+    xf = x.reshape(b, c, -1)
+    qkv = ab.qkv(_gn(ab.norm, xf))
+    qkv = qkv.reshape(b * ab.num_heads, -1, qkv.shape[2])
+    ch = qkv.shape[1] // 3
+    q, k, v = torch.split(qkv, ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale).float(), dim=-1)
+    h = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, qkv.shape[2])
+    return (xf + ab.proj_out(h)).reshape(b, c, *spatial)
+
+
+def _run(seq, h, emb):
+    for layer in seq:
+        name = type(layer).__name__
+        if name == "ResBlock":
+            h = _resblock(layer, h, emb)
+        elif name == "AttentionBlock":
+            h = _attention(layer, h)
+        elif name == "Downsample":
+            h = layer.op(h)
+        elif name == "Upsample":
+            h = layer.conv(F.interpolate(h, scale_factor=2, mode="nearest"))
+        else:
+            h = layer(h)
+    return h
+
+
+def unet_forward(model, x, timesteps):
+    with torch.no_grad():
+        emb = model.time_embed[2](_silu(model.time_embed[0](timestep_embedding(timesteps, model.model_channels))))
+        hs, h = [], x.float()
+        for blk in model.input_blocks:
+            h = _run(blk, h, emb)
+            hs.append(h)
+        h = _run(model.middle_block, h, emb)
+        for blk in model.output_blocks:
+            h = _run(blk, torch.cat([h, hs.pop()], dim=1), emb)
+        return model.out[2](_silu(_gn(model.out[0], h)))
+
+
+# ---- continuous-beta reverse VP-SDE (improved_diffusion_sde.py:48-137) -------------------------------------------
+MEL_UPPER_BOUND, MEL_LOWER_BOUND = 38.22, -100.0                       # sc09_spectrogram_dataset.py:62-63
+
+
+def melspec_standardize(x):
+    return 2 * (x - MEL_LOWER_BOUND) / (MEL_UPPER_BOUND - MEL_LOWER_BOUND) - 1          # :65-72
+
+
+def melspec_inv_standardize(x):
+    return (x + 1) * (MEL_UPPER_BOUND - MEL_LOWER_BOUND) / 2 + MEL_LOWER_BOUND          # :74-81
+
+
+def sde_f_g(model, x, tau, beta_min=0.1, beta_max=20.0, N=1000):
+    """f, g of the reverse SDE in torchsde time at reference time tau = 1 - s (scalar float tensor)."""
+    beta_t = beta_min + tau * (beta_max - beta_min)                                      # :86
+    drift = -0.5 * beta_t * x
+    diffusion = torch.sqrt(beta_t)
+    disc = (tau.float() * N).long()                                                      # :82-83
+    eps = unet_forward(model, x, disc.expand(x.shape[0]))                                # :106
+    ac = torch.exp(-0.5 * (beta_max - beta_min) * tau ** 2 - beta_min * tau)             # :74
+    score = (-1.0 / torch.sqrt(1.0 - ac)) * eps                                          # :75,:111
+    drift = drift - diffusion ** 2 * score                                               # :116
+    return -drift, diffusion                                                             # :126,:136
+
+
+def sde_step_times(t_star: int, dt: float = 1e-3):
+    """torchsde's fixed-step Euler grid on ts = linspace(1 - t/1000, 1 - 1e-5, 2) (improved_diffusion_sde.py:194-196),
+    restated with the float32 time arithmetic the reference runs in (ts is a float32 tensor; curr_t + dt, 1 - t and the
+    model timestep floor((1 - t) * 1000) are all float32): t steps, the last one shortened by 1e-5; which integer
+    timestep a step lands on is decided by that float32 rounding (t = 5 gives 4,4,3,2,1; t = 12 gives 12..1).
+    Returns [(tau_i, h_i)] as float32."""
+    import numpy as np
+    t0, t1, d = np.float32(1 - t_star * 1. / 1000), np.float32(1 - 1e-5), np.float32(dt)
+    out, s = [], t0
+    while s < t1:
+        nxt = min(np.float32(s + d), t1)
+        out.append((np.float32(1) - s, np.float32(nxt - s)))
+        s = nxt
+    return out
+
+
+def spec_sde_purify(model, img_db, t_star: int, noises):
+    """RevImprovedDiffusion.image_editing_sample, sample_step = 1 (:173-221): mel-dB in, mel-dB out."""
+    with torch.no_grad():
+        x0 = melspec_standardize(img_db.float())
+        betas = torch.linspace(0.1 / 1000, 20.0 / 1000, 1000)                            # RevVPSDE defaults, :49,:66
+        a = (1 - betas).cumprod(dim=0)
+        x = x0 * a[t_star - 1].sqrt() + noises[0] * (1.0 - a[t_star - 1]).sqrt()         # :188-189
+        for i, (tau, h) in enumerate(sde_step_times(t_star)):
+            f, g = sde_f_g(model, x, torch.tensor(float(tau), dtype=torch.float32))
+            x = x + f * float(h) + g * math.sqrt(float(h)) * noises[1 + i]
+        return melspec_inv_standardize(x)
