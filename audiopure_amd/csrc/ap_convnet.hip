@@ -461,3 +461,27 @@ extern "C" int ap_axpbyc(const float *x, const float *y, float *out, float a, fl
   AP_HIP(hipGetLastError());
   return 0;
 }
+
+namespace ap {
+// GaussianDiffusion.p_sample with epsilon prediction and a fixed variance (gaussian_diffusion.py:232-387):
+// pred_x0 = clamp(r1 x - r2 eps, -1, 1); mean = c1 pred_x0 + c2 x; out = mean + sigma z
+__global__ void psample_kernel(const float *__restrict__ x, const float *__restrict__ eps, const float *__restrict__ z,
+                               float *__restrict__ out, float r1, float r2, float c1, float c2, float sigma, int clip,
+                               size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p = r1 * x[i] - r2 * eps[i];
+  if (clip) p = fminf(fmaxf(p, -1.0f), 1.0f);
+  float v = c1 * p + c2 * x[i];
+  if (z) v += sigma * z[i];
+  out[i] = v;
+}
+}  // namespace ap
+
+extern "C" int ap_psample_update(const float *x, const float *eps, const float *z, float *out, float r1, float r2, float c1,
+                                 float c2, float sigma, int clip, size_t n, void *stream) {
+  if (!x || !eps || !out || n < 1) { set_error("ap_psample_update: bad argument"); return -22; }
+  ap::psample_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, eps, z, out, r1, r2, c1, c2, sigma, clip, n);
+  AP_HIP(hipGetLastError());
+  return 0;
+}

@@ -253,6 +253,10 @@ int ap_attention_qkv(const float *qkv, float *out, int B, int C, int T, int head
 /* out = a*x + b*y + c elementwise (y may be NULL): melspec_standardize / inv (sc09_spectrogram_dataset.py:65-81) and the
  * Euler links of the spectrogram SDE (improved_diffusion_sde.py:173-221). */
 int ap_axpbyc(const float *x, const float *y, float *out, float a, float b, float c, size_t n, void *stream);
+/* GaussianDiffusion.p_sample, epsilon prediction + fixed variance (gaussian_diffusion.py:232-387): pred_x0 =
+ * clamp(r1 x - r2 eps, -1, 1) (clip != 0), mean = c1 pred_x0 + c2 x, out = mean + sigma z (z NULL at t = 0). */
+int ap_psample_update(const float *x, const float *eps, const float *z, float *out, float r1, float r2, float c1, float c2,
+                      float sigma, int clip, size_t n, void *stream);
 
 /* Fill out[B][L] with the library's Philox N(0,1) stream (same values the fused paths use). */
 int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,

@@ -128,3 +128,32 @@ def spec_sde_purify(model, img_db, t_star: int, noises):
             f, g = sde_f_g(model, x, torch.tensor(float(tau), dtype=torch.float32))
             x = x + f * float(h) + g * math.sqrt(float(h)) * noises[1 + i]
         return melspec_inv_standardize(x)
+
+
+# ---- GaussianDiffusion DDPM chain (gaussian_diffusion.py:119-163,188-206,232-387), eps-prediction, FIXED_LARGE ------
+def ddpm_spec_purify(model, img_db, t_star: int, noises, T=200, clip=True):
+    import numpy as np
+    betas = np.linspace(0.0001, 0.02, T, dtype=np.float64)
+    ac = np.cumprod(1.0 - betas)
+    ac_prev = np.append(1.0, ac[:-1])
+    post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+    coef1 = betas * np.sqrt(ac_prev) / (1.0 - ac)
+    coef2 = (1.0 - ac_prev) * np.sqrt(1.0 - betas) / (1.0 - ac)
+    logvar = np.log(np.append(post_var[1], betas[1:]))
+    f = lambda a, i: torch.tensor(a[i]).float()          # _extract_into_tensor: float64 table -> .float()
+    with torch.no_grad():
+        x0 = melspec_standardize(img_db.float())
+        x = f(np.sqrt(ac), t_star - 1) * x0 + f(np.sqrt(1.0 - ac), t_star - 1) * noises[0]
+        k = 1
+        for i in range(t_star - 1, -1, -1):
+            eps = unet_forward(model, x, torch.full((x.shape[0],), float(i)))
+            px0 = f(np.sqrt(1.0 / ac), i) * x - f(np.sqrt(1.0 / ac - 1), i) * eps
+            if clip:
+                px0 = px0.clamp(-1, 1)
+            mean = f(coef1, i) * px0 + f(coef2, i) * x
+            if i > 0:
+                x = mean + torch.exp(0.5 * f(logvar, i)) * noises[k]
+                k += 1
+            else:
+                x = mean
+        return melspec_inv_standardize(x)

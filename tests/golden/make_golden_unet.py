@@ -58,5 +58,23 @@ for tau in (0.0045, 0.02):
     s = torch.tensor([1.0 - tau])
     out[f"mini/sde_f_tau{tau}"] = sde.f(s, xs.clone()).numpy().copy()
     out[f"mini/sde_g_tau{tau}"] = sde.g(s, xs.clone()).numpy()[:, :4].copy()
+# GaussianDiffusion DDPM chain of the reference (script_util.py:231-269 defaults: T=200, linear, eps-prediction, FIXED_LARGE):
+# q_sample at t*-1 then p_sample for t = t*-1..0 on the mini UNet, noise injected by patching th.randn_like
+from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion import script_util as su              # noqa: E402
+import diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.gaussian_diffusion as gd             # noqa: E402
+dd = su.model_and_diffusion_defaults()
+diff = su.create_gaussian_diffusion(steps=dd["diffusion_steps"], learn_sigma=dd["learn_sigma"], sigma_small=dd["sigma_small"],
+                                    noise_schedule=dd["noise_schedule"], use_kl=dd["use_kl"], predict_xstart=dd["predict_xstart"],
+                                    rescale_timesteps=dd["rescale_timesteps"], rescale_learned_sigmas=dd["rescale_learned_sigmas"],
+                                    timestep_respacing=dd["timestep_respacing"])
+img = torch.from_numpy(synth.uniform("meldb", (2, 1, 32, 32), 5, -90.0, 30.0))
+z = [torch.from_numpy(synth.normal(f"sz{i}", (2, 1, 32, 32), 5)) for i in range(5)]
+xq = diff.q_sample(2 * (img + 100.0) / 138.22 - 1, torch.tensor([3, 3]), noise=z[0])
+queue = list(z[1:])
+gd.th.randn_like = lambda t_: queue.pop(0)
+for i in range(3, -1, -1):
+    xq = diff.p_sample(mini, xq, torch.tensor([i, i]))["sample"]
+out["mini/ddpm_t4"] = ((xq + 1) * 138.22 / 2 - 100.0).numpy().copy()
+
 np.savez(os.path.join(HERE, "golden_unet_v1.npz"), **out)
 print("wrote golden_unet_v1.npz", {k: v.shape for k, v in out.items() if "keys" not in k})

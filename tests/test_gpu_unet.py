@@ -79,3 +79,13 @@ def test_spec_purifier_matches_oracle(dev):
     got = rev(img.to(dev))
     assert got.shape == img.shape
     assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+def test_ddpm_spec_purifier_matches_reference_golden(dev, gold):
+    from audiopure_amd.diffusion_models.improved_diffusion_ddpm import ImprovedDiffusionDDPM
+    img = torch.from_numpy(synth.uniform("meldb", (2, 1, 32, 32), 5, -90.0, 30.0))
+    z = [torch.from_numpy(synth.normal(f"sz{i}", (2, 1, 32, 32), 5)) for i in range(5)]
+    dd = ImprovedDiffusionDDPM(mini_unet().to(dev), reverse_timestep=4)
+    dd.set_noise_source(z)
+    got = dd(img.to(dev))
+    assert rel_err(got.cpu().numpy(), gold["mini/ddpm_t4"]) < 1e-4

@@ -75,3 +75,11 @@ def test_step_table_equals_oracle_euler_coefficients():
         assert disc == float(int(np.float32(tau) * np.float32(1000)))
         assert math.isclose(ca, 1 + 0.5 * beta * h, rel_tol=1e-6) and math.isclose(cs, math.sqrt(beta * h), rel_tol=1e-6)
         assert math.isclose(cb, -beta * h / math.sqrt(1 - abar), rel_tol=1e-5)
+
+
+def test_ddpm_chain_oracle_matches_reference_gaussian_diffusion(gold):
+    m = mini_unet()
+    img = torch.from_numpy(synth.uniform("meldb", (2, 1, 32, 32), 5, -90.0, 30.0))
+    z = [torch.from_numpy(synth.normal(f"sz{i}", (2, 1, 32, 32), 5)) for i in range(5)]
+    got = U.ddpm_spec_purify(m, img, 4, z)
+    assert rel_err(got.numpy(), gold["mini/ddpm_t4"]) < 5e-6
