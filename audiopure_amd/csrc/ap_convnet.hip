@@ -106,6 +106,121 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
   }
 }
 
+// 128 x 128 tile variant for wide layers (Cout/g >= 128: UNet, ResNeXt stages 2-3, VGG 128+): 4 waves x (64 x 64 =
+// 2 x 2 accumulators), so each staged element feeds 4x the MFMAs of the 64 x 64 kernel, and the im2col index (ci, r)
+// of every element a thread stages advances incrementally by the chunk size instead of being re-derived by division
+// (kh, kw <= 3).  Same contract as conv2d_f32_kernel.
+__global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
+  constexpr int BM = 128, BN = 128, BK = 16;
+  __shared__ float As[2][BK][BM];
+  __shared__ float Bs[2][BK][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, hh = lane >> 5;
+  const int Mg = a.Cout / a.groups, Cg = a.Cin / a.groups, KK = a.kh * a.kw, Kg = Cg * KK;
+  const int HoWo = a.Ho * a.Wo, N = a.B * HoWo;
+  const int g = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int nl = tid & 127, kq = tid >> 7;             // element i of a thread: k row kq + 2 i, column / row nl
+  const int n = n0 + nl;
+  const bool nvalid = n < N;
+  const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg) * a.H * a.W;
+  const float *wg = a.wT + (size_t)g * Kg * Mg;
+  const bool mvalid = (m0 + nl) < Mg;
+  const int HW = a.H * a.W;
+  const int dci = BK / KK, dr = BK % KK;               // (ci, r) += (dci, dr) per chunk, with carry
+  int ci[8], rr[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int k = kq + 2 * i;
+    ci[i] = k / KK;
+    rr[i] = k % KK;
+  }
+  float ar[8], br[8];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int k = k0 + kq + 2 * i;
+      float av = 0.f, bv = 0.f;
+      if (k < Kg) {
+        if (mvalid) av = wg[(size_t)k * Mg + m0 + nl];
+        const int r = rr[i];
+        const int ky = (r >= a.kw) + (r >= 2 * a.kw), kx = r - ky * a.kw;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        if (nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) bv = xb[(size_t)ci[i] * HW + iy * a.W + ix];
+      }
+      ar[i] = av;
+      br[i] = bv;
+      int r2 = rr[i] + dr, c2 = ci[i] + dci;
+      if (r2 >= KK) { r2 -= KK; c2++; }
+      rr[i] = r2;
+      ci[i] = c2;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      As[buf][kq + 2 * i][nl] = ar[i];
+      Bs[buf][kq + 2 * i][nl] = br[i];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+    for (int y_ = 0; y_ < 2; y_++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[x_][y_][r] = 0.f;
+
+  const int nchunk = (Kg + BK - 1) / BK;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; c++) {
+    if (c + 1 < nchunk) load_chunk((c + 1) * BK);
+    const int buf = c & 1;
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        af[t] = As[buf][2 * s + hh][64 * wm + 32 * t + j];
+        bf[t] = Bs[buf][2 * s + hh][64 * wn + 32 * t + j];
+      }
+#pragma unroll
+      for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+        for (int y_ = 0; y_ < 2; y_++)
+          acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x_], bf[y_], acc[x_][y_], 0, 0, 0);
+    }
+    if (c + 1 < nchunk) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int y_ = 0; y_ < 2; y_++) {
+    const int nn = n0 + 64 * wn + 32 * y_ + j;
+    if (nn < N) {
+      const int ob = nn / HoWo, op = nn % HoWo;
+#pragma unroll
+      for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = m0 + 64 * wm + 32 * x_ + crowoff(r, hh);
+          if (m < Mg) {
+            const int co = g * Mg + m;
+            const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
+            float v = acc[x_][y_][r];
+            if (a.bias) v += a.bias[co];
+            if (a.res) v += a.res[off];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[off] = v;
+          }
+        }
+    }
+  }
+}
+
 // w [Cout][Cin/g][kh][kw] (* per-output-channel scale) -> wT [groups][Kg][Mg]
 __global__ void conv_pack_kernel(const float *__restrict__ w, const float *__restrict__ scale, float *__restrict__ wT,
                                  int Cout, int Kg, int groups) {
@@ -216,8 +331,14 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   if (a.Ho < 1 || a.Wo < 1) { set_error("ap_conv2d_fwd: empty output"); return -22; }
   const long long N = (long long)B * a.Ho * a.Wo;
   const int Mg = Cout / groups;
-  dim3 grid((unsigned)((N + CBN - 1) / CBN), (unsigned)((Mg + CBM - 1) / CBM), (unsigned)groups);
-  conv2d_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  // the 128 x 128 tile needs enough workgroups to fill 256 CUs; otherwise 4x as many 64 x 64 tiles win
+  if (Mg >= 128 && kh <= 3 && kw <= 3 && ((N + 127) / 128) * ((Mg + 127) / 128) * (long long)groups >= 512) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+    conv2d_f32_big_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  } else {
+    dim3 grid((unsigned)((N + CBN - 1) / CBN), (unsigned)((Mg + CBM - 1) / CBM), (unsigned)groups);
+    conv2d_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  }
   AP_HIP(hipGetLastError());
   return 0;
 }
@@ -354,29 +475,57 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
     vs[i] = base[(size_t)2 * CH * T + i];
   }
   __syncthreads();
+  const bool vec4 = (T % 4) == 0;
   for (int t = threadIdx.x; t < T; t += 256) {
     float q[CH];
 #pragma unroll
-    for (int c = 0; c < CH; c++) q[c] = base[(size_t)c * T + t];
-    float mx = -INFINITY;
-    for (int s = 0; s < T; s++) {
-      float w = 0.f;
-#pragma unroll
-      for (int c = 0; c < CH; c++) w = __builtin_fmaf(q[c], ks[c * T + s], w);
-      mx = fmaxf(mx, w * scale2);
-    }
+    for (int c = 0; c < CH; c++) q[c] = base[(size_t)c * T + t] * scale2;
+    // single pass with a running maximum (exact softmax: every term is rescaled when the maximum moves);
+    // keys are consumed four at a time so each LDS read (ds_read_b128, broadcast) feeds four FMAs
     float acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) acc[c] = 0.f;
-    float l = 0.f;
-    for (int s = 0; s < T; s++) {
-      float w = 0.f;
+    float mx = -INFINITY, l = 0.f;
+    if (vec4) {
+      for (int s = 0; s < T; s += 4) {
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < CH; c++) w = __builtin_fmaf(q[c], ks[c * T + s], w);
-      const float p = expf(w * scale2 - mx);
-      l += p;
+        for (int c = 0; c < CH; c++) w += q[c] * *reinterpret_cast<const f32x4 *>(ks + c * T + s);
+        const float bm = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+        if (bm > mx) {
+          const float corr = expf(mx - bm);       // exp(-inf) = 0 on the first block
+          l *= corr;
 #pragma unroll
-      for (int c = 0; c < CH; c++) acc[c] = __builtin_fmaf(p, vs[c * T + s], acc[c]);
+          for (int c = 0; c < CH; c++) acc[c] *= corr;
+          mx = bm;
+        }
+        f32x4 p;
+#pragma unroll
+        for (int i = 0; i < 4; i++) p[i] = expf(w[i] - mx);
+        l += (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          const f32x4 vv = *reinterpret_cast<const f32x4 *>(vs + c * T + s);
+          acc[c] += (p[0] * vv[0] + p[1] * vv[1]) + (p[2] * vv[2] + p[3] * vv[3]);
+        }
+      }
+    } else {
+      for (int s = 0; s < T; s++) {
+        float w = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; c++) w = __builtin_fmaf(q[c], ks[c * T + s], w);
+        if (w > mx) {
+          const float corr = expf(mx - w);
+          l *= corr;
+#pragma unroll
+          for (int c = 0; c < CH; c++) acc[c] *= corr;
+          mx = w;
+        }
+        const float p = expf(w - mx);
+        l += p;
+#pragma unroll
+        for (int c = 0; c < CH; c++) acc[c] = __builtin_fmaf(p, vs[c * T + s], acc[c]);
+      }
     }
     const float inv = 1.0f / l;
     float *op = out + (size_t)bh * CH * T;

@@ -1,5 +1,5 @@
 import sys, ctypes as C, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from audiopure_amd import synth, _native as N
 from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
 dev = torch.device("cuda:0")

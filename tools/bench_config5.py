@@ -1,6 +1,6 @@
 """BASELINE configs[4]: Improved-Diffusion UNet n=5 (spectrogram SDE purifier) + ResNeXt29 classifier, batch=256."""
 import sys, time, types, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init
 from audiopure_amd.convnet import NativeConvNet
 from audiopure_amd.acoustic_system import AcousticSystem
