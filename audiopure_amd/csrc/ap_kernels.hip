@@ -768,7 +768,13 @@ extern "C" int ap_debug_force_f32(int on) {
   return 0;
 }
 
-namespace ap { extern int g_ablate_bf16; }
+namespace ap { extern int g_ablate_bf16; extern unsigned long long *g_trace_bf16; }
+
+// timing-only: device buffer (nblk x 2 x 16 u64) the bf16 residual block writes phase timestamps into; null = off
+extern "C" int ap_debug_trace(void *buf) {
+  ap::g_trace_bf16 = (unsigned long long *)buf;
+  return 0;
+}
 
 extern "C" int ap_debug_ablate(int mask) {
   ap::g_ablate = mask;

@@ -82,22 +82,46 @@ int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
-template <int C>
+// What bounds it (tools/trace_resblock_bf16.py, s_memtime stamps per phase): the CU's one vector-memory address
+// pipeline accepts a wave-wide load/store in ~16 cycles WHATEVER its width, so a tile's time is set by the NUMBER
+// of VMEM instructions its 8 waves issue, not by bytes or latency.  Hence every global access here is 16 B per lane:
+//   X4: the X image is staged with dwordx4 loads (4 samples x 8 channels per thread) when d % 4 == 0 and L % 4 == 0
+//       (dword path otherwise: d = 1, 2);
+//   E4: the GEMM2 results go through a wave-private LDS patch that turns the MFMA layout (4 rows x 1 column per
+//       lane) into 1 row x 4 columns, so the residual / skip read-modify-write is dwordx4 both ways (L % 4 == 0).
+constexpr bool STAGGER = false;       // waves 4-7 half a chunk behind 0-3 (measured: no gain, 6.41 vs 6.20 ms)
+constexpr int PSTR = 36;                // fp32 row stride of the wave-private output patch (144 B: 16-B aligned rows)
+
+template <int C, bool X4, bool E4, bool TRACE, int DBG = 0>
 __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const __bf16 *__restrict__ w1p, const float *__restrict__ b1, const __bf16 *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk, int ablate) {
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk, int ablate,
+    unsigned long long *__restrict__ trace) {
   constexpr int NW = C / 32, NT = NW * 64, NCH = C / BKC;
   static_assert(NT == 512, "bf16 kernel is built for C = 256 (8 waves)");
   constexpr int GSTRIDE = C + 8;                               // bf16 per column row of the g image (528 B)
   constexpr int XBYTES = BT * XSTRIDE * 2;                     // 26,624 B per X buffer
-  constexpr int LDS_BYTES = (2 * XBYTES > BT * GSTRIDE * 2) ? 2 * XBYTES : BT * GSTRIDE * 2;
+  // LDS: ring of three X buffers; the g image starts at buffer 2 (buffer 1 is still read by the lagging waves when
+  // the leading ones write g); then the wave-private output patches.  157,696 B of the CU's 160 KB.
+  constexpr int GOFF = 2 * XBYTES;
+  constexpr int GBYTES = GOFF + BT * GSTRIDE * 2;
+  constexpr int PTOFF = GBYTES + (E4 ? NW * 32 * PSTR * 4 : 0);   // part_t (C floats), read back at pack time
+  constexpr int LDS_BYTES = PTOFF + C * 4;
+  static_assert(LDS_BYTES <= 160 * 1024 && GBYTES >= 3 * XBYTES, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
+  // phase timestamps of waves 0 and 7 (tools/trace_resblock_bf16.py); compiled out of the production instantiation
+  auto mark = [&](int i) {
+    if constexpr (TRACE) {
+      if (lane == 0) trace[((size_t)blockIdx.x * NW + wave) * 16 + i] = __builtin_readcyclecounter();
+    }
+  };
+  mark(0);
   // XCD-local order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a contiguous run of
   // (clip, tile) work so the +-d taps and the residual patch of a clip are re-read from that XCD's L2.
   int logical;
@@ -107,63 +131,111 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   }
   const int b = __builtin_amdgcn_readfirstlane(logical / ntiles);
   const int t0 = __builtin_amdgcn_readfirstlane((logical % ntiles) * BT);
-  const float *hin_b;
-  {
-    const uint64_t hb = (uint64_t)(hin + (size_t)b * C * L);
+  const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
+  auto clip_rsrc = [&](const float *base) {
+    const uint64_t hb = (uint64_t)(base + (size_t)b * C * L);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
-    hin_b = (const float *)(((uint64_t)hi << 32) | lo);
-  }
-  const __amdgpu_buffer_rsrc_t hrs =
-      __builtin_amdgcn_make_buffer_rsrc((void *)hin_b, 0, (int)((unsigned)C * (unsigned)L * 4u), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)clip_bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t hrs = clip_rsrc(hin);
 
   f32x16 acc[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float bv = b1[rt * C + 32 * wave + rowoff_b(r, hh)];
+    for (int q = 0; q < 4; q++) {
+      const float4 bv = *reinterpret_cast<const float4 *>(b1 + rt * C + 32 * wave + 8 * q + 4 * hh);
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+      for (int ct = 0; ct < 4; ct++) {
+        acc[rt][ct][4 * q + 0] = bv.x;
+        acc[rt][ct][4 * q + 1] = bv.y;
+        acc[rt][ct][4 * q + 2] = bv.z;
+        acc[rt][ct][4 * q + 3] = bv.w;
+      }
     }
 
-  // ---- X staging: thread = (column tid&127, channel octet q = tid>>7) for each of the 3 taps; 24 buffer loads issued
-  // at the head of a chunk; FiLM add, zero-pad select, bf16 pack and one ds_write_b128 per tap at its tail.
-  const int col = tid & (BT - 1), q8 = (tid >> 7) * 8;
+  // ---- X staging.  FiLM add (WaveNet.py:84), zero padding (:26-27), bf16 pack, ds_write_b128 into the [col][k] image.
+  // X4: thread = (tap = wave/2, column quad cg, channel octet oct); lane bits (low to high) cg&3, oct, cg>>2 so that a
+  //     load covers whole 64-B runs per channel row and a store spreads over all 64 banks.  Waves 6, 7 repeat tap 2
+  //     (a branch around them would make every later vmcnt wait the conservative one).
+  // dword path: thread = (column tid&127, channel octet tid>>7) for each of the 3 taps.
+  constexpr int NXR = X4 ? 32 : 24;
+  float xr[NXR];
+  if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
   unsigned voff[3];
   bool tok[3];
-#pragma unroll
-  for (int tap = 0; tap < 3; tap++) {
-    const int tp = t0 + col + (tap - 1) * d;
-    tok[tap] = (tp >= 0) && (tp < L);
-    voff[tap] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)q8 * (unsigned)L) * 4u;
-  }
-  float xr[3][8];
-  float ptv[8];
-  auto issue_loads = [&](int ch) {
-#pragma unroll
-    for (int e = 0; e < 8; e++) ptv[e] = pt[ch * BKC + q8 + e];
-#pragma unroll
-    for (int tap = 0; tap < 3; tap++)
-#pragma unroll
-      for (int e = 0; e < 8; e++)
-        xr[tap][e] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(hrs, voff[tap], (ch * BKC + e) * L * 4, 0));
-  };
-  auto store_chunk = [&](unsigned char *dst) {
+  int xcol, xk;                                                 // first column / k offset of this thread's LDS stores
+  if constexpr (X4) {
+    const int xtap = min(wave >> 1, 2);
+    const int cg = ((wave & 1) * 4 + (lane >> 4)) * 4 + (lane & 3), oct = (lane >> 2) & 3;
+    const int tp = t0 + 4 * cg + (xtap - 1) * d;
+    tok[0] = (tp >= 0) && (tp < L);
+    voff[0] = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+    xcol = 4 * cg;
+    xk = xtap * BKC + oct * 8;
+  } else {
+    const int col = tid & (BT - 1);
 #pragma unroll
     for (int tap = 0; tap < 3; tap++) {
-      bf16x8 pk;
+      const int tp = t0 + col + (tap - 1) * d;
+      tok[tap] = (tp >= 0) && (tp < L);
+      voff[tap] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)((tid >> 7) * 8) * (unsigned)L) * 4u;
+    }
+    xcol = col;
+    xk = (tid >> 7) * 8;
+  }
+  const float *ptx = reinterpret_cast<const float *>(lds + PTOFF) + (X4 ? xk & (BKC - 1) : xk);
+  auto issue_loads = [&](int ch) {
+    if constexpr (X4) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) pk[e] = (__bf16)(tok[tap] ? xr[tap][e] + ptv[e] : 0.f);   // WaveNet.py:84, :26-27
-      *reinterpret_cast<bf16x8 *>(dst + (col * XSTRIDE + tap * BKC + q8) * 2) = pk;
+      for (int e = 0; e < 8; e++) {
+        // (bit_cast the whole vector: element-wise bit_cast of the builtin's int vector is mis-folded to a splat)
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, voff[0], (ch * BKC + e) * L * 4, 0));
+#pragma unroll
+        for (int i = 0; i < 4; i++) xr[e * 4 + i] = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+          xr[tap * 8 + e] = __builtin_bit_cast(
+              float, __builtin_amdgcn_raw_buffer_load_b32(hrs, voff[tap], (ch * BKC + e) * L * 4, 0));
+    }
+  };
+  auto store_chunk = [&](unsigned char *dst, int ch) {
+    float ptv[8];
+    {
+      const float4 p0 = *reinterpret_cast<const float4 *>(ptx + ch * BKC);
+      const float4 p1 = *reinterpret_cast<const float4 *>(ptx + ch * BKC + 4);
+      ptv[0] = p0.x; ptv[1] = p0.y; ptv[2] = p0.z; ptv[3] = p0.w;
+      ptv[4] = p1.x; ptv[5] = p1.y; ptv[6] = p1.z; ptv[7] = p1.w;
+    }
+    if constexpr (X4) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        bf16x8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; e++) pk[e] = (__bf16)(tok[0] ? xr[e * 4 + i] + ptv[e] : 0.f);
+        *reinterpret_cast<bf16x8 *>(dst + ((xcol + i) * XSTRIDE + xk) * 2) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < 3; tap++) {
+        bf16x8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; e++) pk[e] = (__bf16)(tok[tap] ? xr[tap * 8 + e] + ptv[e] : 0.f);
+        *reinterpret_cast<bf16x8 *>(dst + (xcol * XSTRIDE + tap * BKC + xk) * 2) = pk;
+      }
     }
   };
 
   issue_loads(0);
-  store_chunk(lds);
+  __syncthreads();                                              // part_t visible
+  store_chunk(lds, 0);
   __syncthreads();
-  const u32x4 *ap0 = reinterpret_cast<const u32x4 *>(w1p) + lane;
+  mark(1);
 
   // ---- GEMM1: per chunk 6 k-steps; A fragments (weights, this wave's 64 rows only) stream from L2 into registers in
   // sets of 3 k-steps, one set ahead of use.
@@ -171,8 +243,10 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 #pragma unroll
     for (int s = 0; s < 3; s++)
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++)
-        a[s][rt] = __builtin_bit_cast(bf16x8, ((ablate & 4) ? ap0 : base)[(s * 2 + rt) * 64]);
+      for (int rt = 0; rt < 2; rt++) a[s][rt] = __builtin_bit_cast(bf16x8, base[(s * 2 + rt) * 64]);
+  };
+  auto load_a3_loop = [&](bf16x8(&a)[3][2], const u32x4 *base) {   // DBG&1 (trace builds): no weight loads in the loop
+    if constexpr (!(DBG & 1)) load_a3(a, base);
   };
   auto mma3 = [&](const bf16x8(&a)[3][2], const unsigned char *xb, int rowbytes) {
 #pragma unroll
@@ -191,25 +265,91 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 
   const u32x4 *ap = reinterpret_cast<const u32x4 *>(w1p) + (size_t)wave * NCH * 6 * 2 * 64 + lane;
   bf16x8 a0[3][2], a1[3][2];
-  load_a3(a0, ap);
   const int rdoff = (j * XSTRIDE + 8 * hh) * 2;                // this lane's B-fragment byte offset inside an X buffer
+  auto xbuf = [&](int ch) { return lds + (ch % 3) * XBYTES; };
+  // One half-chunk = 24 MFMAs on 3 k-steps.  The CU's vector-memory path takes ~16 cycles per 16-B wave-wide load and
+  // a wave issues in order, so loads sit between the MFMAs (never in a burst ahead of them), and the two waves of a
+  // SIMD are half a chunk apart (waves 4-7 lag): while one runs its load-heavy half (6 weight + 10 X loads) the
+  // other runs its light one (6 weight loads) and keeps the matrix pipe fed.  That needs a ring of three X buffers:
+  // in iteration i the leading waves read chunk i, the lagging ones chunk i-1 then i, and everybody writes i+1.
+  // vmcnt retires in issue order and a wait after a control-flow merge is the conservative one, so the loops are
+  // branch-free (the last chunks re-fetch / re-store chunk 7 into an idle buffer).
+  auto half_heavy = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], const u32x4 *nsrc,
+                        int xchunk) {
+    load_a3_loop(nxt, nsrc);
+    if constexpr (!(DBG & 2)) issue_loads(xchunk);
+    mma3(use, xb, XSTRIDE * 2);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (X4) {
+        if (i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      } else {
+        if (i < 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if ((i & 7) >= 3 && (i & 7) <= 6 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto half_light = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], const u32x4 *nsrc) {
+    load_a3_loop(nxt, nsrc);
+    mma3(use, xb, XSTRIDE * 2);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if ((i & 7) >= 3 && (i & 7) <= 6 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto set0 = [&](int ch) { return ap + (size_t)(ch * 6) * 128; };
+  auto set1 = [&](int ch) { return ap + (size_t)(ch * 6 + 3) * 128; };
+  if (!STAGGER || wave < NW / 2) {
+    load_a3(a0, set0(0));
+    if constexpr (DBG & 1) load_a3(a1, set1(0));
 #pragma unroll 1
-  for (int ch = 0; ch < NCH; ch++) {
-    if (ch + 1 < NCH && !(ablate & 8)) issue_loads(ch + 1);
-    load_a3(a1, ap + (size_t)(ch * 6 + 3) * 128);
+    for (int ch = 0; ch < NCH; ch++) {
+      const int nx = ch + 1 < NCH ? ch + 1 : ch;
+      const unsigned char *xb = xbuf(ch) + rdoff;
+      half_heavy(a0, xb, a1, set1(ch), nx);
+      if (ch == 4) mark(10);
+      half_light(a1, xb + 3 * 32, a0, set0(nx));
+      if (ch == 4) mark(11);
+      store_chunk(xbuf(ch + 1), nx);
+      if (ch == 4) mark(12);
+      __syncthreads();
+      if (ch == 0) mark(2);
+      if (ch == 3) mark(3);
+      if (ch == 4) mark(13);
+    }
+  } else {
+    issue_loads(1);
+    load_a3(a0, set0(0));
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned char *xb = lds + (ch & 1) * XBYTES + rdoff;
-    mma3(a0, xb, XSTRIDE * 2);
-    __builtin_amdgcn_sched_barrier(0);
-    load_a3(a0, ap + (size_t)((ch + 1 < NCH ? ch + 1 : ch) * 6) * 128);
-    __builtin_amdgcn_sched_barrier(0);
-    mma3(a1, xb + 3 * 32, XSTRIDE * 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ch + 1 < NCH) store_chunk(lds + ((ch + 1) & 1) * XBYTES);
+    store_chunk(xbuf(1), 1);
+    half_heavy(a0, xbuf(0) + rdoff, a1, set1(0), 2);
     __syncthreads();
+    mark(2);
+#pragma unroll 1
+    for (int ch = 1; ch < NCH; ch++) {
+      half_light(a1, xbuf(ch - 1) + rdoff + 3 * 32, a0, set0(ch));
+      if (ch == 4) mark(10);
+      store_chunk(xbuf(ch + 1), ch + 1 < NCH ? ch + 1 : NCH - 1);
+      if (ch == 4) mark(11);
+      half_heavy(a0, xbuf(ch) + rdoff, a1, set1(ch), ch + 2 < NCH ? ch + 2 : NCH - 1);
+      if (ch == 4) mark(12);
+      __syncthreads();
+      if (ch == 3) mark(3);
+      if (ch == 4) mark(13);
+    }
+    mma3(a1, xbuf(NCH - 1) + rdoff + 3 * 32, XSTRIDE * 2);
   }
+  mark(4);
 
-  // ---- gate (WaveNet.py:90) -> g image [col][channel] bf16 (aliases the X buffers)
+  // ---- gate (WaveNet.py:90) -> g image [col][channel] bf16
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
 #pragma unroll
@@ -218,53 +358,77 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 #pragma unroll
       for (int e = 0; e < 4; e++)
         pk[e] = (__bf16)((ablate & 2) ? acc[0][ct][4 * qq + e] : gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]));
-      *reinterpret_cast<bf16x4 *>(lds + ((32 * ct + j) * GSTRIDE + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
+      *reinterpret_cast<bf16x4 *>(lds + GOFF + ((32 * ct + j) * GSTRIDE + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 
   __syncthreads();
+  mark(5);
 
-  // per-lane element offsets of this wave's 32-channel x 128-column output patch (same for h, h' and skip)
+  // ---- GEMM2 in two passes of 32 rows x 128 columns (64 accumulator VGPRs each, so the values the pass adds into fit
+  // beside them): pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip.  (WaveNet.py:93-97, :133)
+  // Those values (h for the residual, the running skip) are fetched before the pass's GEMM and consumed after it: no
+  // exposed latency, and no float atomics (their ~1.3 TB/s chip-wide rate would cap the launch).
+  constexpr int NKS = C / 16;
+  static_assert(NKS % 8 == 0, "GEMM2 k-steps processed in pairs of 4-step sets");
+  const unsigned char *gb = lds + GOFF + (j * GSTRIDE + 8 * hh) * 2;
+  const float RS = 0.707106781186547524f;
+  const __amdgpu_buffer_rsrc_t srs = clip_rsrc(skip);
+  const __amdgpu_buffer_rsrc_t ors = clip_rsrc(hout);
+  // output patch mapping.  E4: lane = (row lane>>3 (+8 per step), column quad lane&7); else the MFMA layout itself.
   unsigned evoff[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
-    const int t = min(t0 + 32 * ct + j, L - 1);
-    evoff[ct] = ((unsigned)(32 * wave + 4 * hh) * (unsigned)L + (unsigned)t) * 4u;
-  }
-  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)(skip + (size_t)b * C * L), 0, (int)((unsigned)C * (unsigned)L * 4u), 0x00020000);
-
-  // ---- GEMM2 in two passes of 32 rows x 128 columns (64 accumulator VGPRs each, so the residual patch fits beside
-  // them): pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip.  (WaveNet.py:93-97, :133)
-  constexpr int NKS = C / 16;
-  static_assert(NKS % 8 == 0, "GEMM2 k-steps processed in pairs of 4-step sets");
-  const unsigned char *gb = lds + (j * GSTRIDE + 8 * hh) * 2;
-  const float RS = 0.707106781186547524f;
-  float *ho = hout + (size_t)b * C * L;
-  float *sk = skip + (size_t)b * C * L;
+    if constexpr (E4) {
+      const int t = t0 + 32 * ct + 4 * (lane & 7);
+      evoff[ct] = t < L ? ((unsigned)(32 * wave + (lane >> 3)) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
+    } else {
+      const int t = t0 + 32 * ct + j;
+      evoff[ct] = t < L ? ((unsigned)(32 * wave + 4 * hh) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
+    }
+  }                                                             // 0x80000000: out of the clip's range -> load 0 / store dropped
+  float *patch = reinterpret_cast<float *>(lds + GBYTES) + wave * 32 * PSTR;
   const float *b2l = b2, *ptl = pt;
   asm volatile("" : "+s"(b2l), "+s"(ptl));
   auto gemm2_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
-    // the values this pass adds into (h for the residual, running skip) are fetched before its GEMM and consumed
-    // after it: 64 VGPRs, no exposed latency, and no float atomics (their ~1.3 TB/s chip-wide rate would cap the launch)
     float pre[4][16];
     if ((pass == 0 || accumulate) && !(ablate & 1)) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++)
+      for (int ct = 0; ct < 4; ct++) {
+        if constexpr (E4) {
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-          pre[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                     pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+          for (int p = 0; p < 4; p++) {
+            const f32x4 v = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(pass == 0 ? hrs : srs, evoff[ct], 8 * p * L * 4, 0));
+#pragma unroll
+            for (int i = 0; i < 4; i++) pre[ct][4 * p + i] = v[i];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            pre[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                       pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+        }
+      }
     }
     f32x16 ac[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int c = 32 * wave + rowoff_b(r, hh);
-      const float v = (pass == 0) ? b2l[c] + ptl[c] : b2l[C + c];   // u = h + part_t re-enters the residual
+    for (int q = 0; q < 4; q++) {
+      const int c = 32 * wave + 8 * q + 4 * hh;
+      float4 v = *reinterpret_cast<const float4 *>(b2l + pass * C + c);
+      if (pass == 0) {                                           // u = h + part_t re-enters the residual
+        const float4 pv = *reinterpret_cast<const float4 *>(ptl + c);
+        v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+      }
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) ac[ct][r] = v;
+      for (int ct = 0; ct < 4; ct++) {
+        ac[ct][4 * q + 0] = v.x;
+        ac[ct][4 * q + 1] = v.y;
+        ac[ct][4 * q + 2] = v.z;
+        ac[ct][4 * q + 3] = v.w;
+      }
     }
     const u32x4 *ap2 = reinterpret_cast<const u32x4 *>(w2p) + (size_t)(wave * 2 + pass) * NKS * 64 + lane;
     bf16x8 p0[4], p1[4];
@@ -296,32 +460,47 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
       mma4b(p1, gb + (ks + 4) * 32);
       __builtin_amdgcn_sched_barrier(0);
     }
+    mark(6 + 2 * pass);
+    const bool add = (pass == 0) || accumulate;
+    const float scale = pass == 0 ? RS : 1.0f;
+    if (!(ablate & 1)) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) {
-      const int t = t0 + 32 * ct + j;
-      const unsigned rbase = (unsigned)(32 * wave + 4 * hh) * (unsigned)L + (unsigned)t;
-      if (t < L && !(ablate & 1)) {
-        if (pass == 0) {
+      for (int ct = 0; ct < 4; ct++) {
+        if constexpr (E4) {
 #pragma unroll
-          for (int r = 0; r < 16; r++)
-            ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = (pre[ct][r] + ac[ct][r]) * RS;
-        } else if (accumulate) {
+          for (int r = 0; r < 16; r++) patch[rowoff_b(r, hh) * PSTR + j] = ac[ct][r];
 #pragma unroll
-          for (int r = 0; r < 16; r++)
-            sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = pre[ct][r] + ac[ct][r];
+          for (int p = 0; p < 4; p++) {
+            const float4 v = *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * p) * PSTR + 4 * (lane & 7));
+            f32x4 o;
+            o[0] = ((add ? pre[ct][4 * p + 0] : 0.f) + v.x) * scale;
+            o[1] = ((add ? pre[ct][4 * p + 1] : 0.f) + v.y) * scale;
+            o[2] = ((add ? pre[ct][4 * p + 2] : 0.f) + v.z) * scale;
+            o[3] = ((add ? pre[ct][4 * p + 3] : 0.f) + v.w) * scale;
+            // row step in the VGPR offset, soffset = 0: a >8-byte buffer store with an SGPR soffset reads its data
+            // late, and the compiler here does not guard the next write of those VGPRs (observed: torn y lanes)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), pass == 0 ? ors : srs,
+                                                   evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0);
+          }
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; r++) sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = ac[ct][r];
+          for (int r = 0; r < 16; r++)
+            __builtin_amdgcn_raw_buffer_store_b32(
+                __builtin_bit_cast(unsigned, ((add ? pre[ct][r] : 0.f) + ac[ct][r]) * scale), pass == 0 ? ors : srs,
+                evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
         }
       }
     }
   };
   gemm2_pass(std::integral_constant<int, 0>{});
+  mark(7);
   __builtin_amdgcn_sched_barrier(0);
   gemm2_pass(std::integral_constant<int, 1>{});
+  mark(9);
 }
 
 int g_ablate_bf16 = 0;
+unsigned long long *g_trace_bf16 = nullptr;   // ap_debug_trace: device buffer of nblk x 2 x 16 timestamps, or null
 
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st) {
@@ -337,8 +516,23 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
   const __bf16 *w2p = (const __bf16 *)ctx->w2p_bf + (size_t)layer * (C + S) * C;
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
-  resblock_bf16_kernel<256><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate,
-                                                            ntiles, nblk, g_ablate_bf16);
+  const bool e4 = (L % 4 == 0) && L >= 4, x4 = e4 && (d % 4 == 0);
+#define AP_BF16_LAUNCH(X4, E4, TR)                                                                                  \
+  resblock_bf16_kernel<256, X4, E4, TR><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, \
+                                                                        accumulate, ntiles, nblk, g_ablate_bf16,     \
+                                                                        g_trace_bf16)
+  if (g_trace_bf16 && x4) {
+    switch ((g_ablate_bf16 >> 6) & 3) {
+      case 1: resblock_bf16_kernel<256, true, true, true, 1><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, g_trace_bf16); break;
+      case 2: resblock_bf16_kernel<256, true, true, true, 2><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, g_trace_bf16); break;
+      case 3: resblock_bf16_kernel<256, true, true, true, 3><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, g_trace_bf16); break;
+      default: AP_BF16_LAUNCH(true, true, true);
+    }
+  }
+  else if (x4) AP_BF16_LAUNCH(true, true, false);
+  else if (e4) AP_BF16_LAUNCH(false, true, false);
+  else AP_BF16_LAUNCH(false, false, false);
+#undef AP_BF16_LAUNCH
   AP_HIP(hipGetLastError());
   return 0;
 }
