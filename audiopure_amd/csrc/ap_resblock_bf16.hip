@@ -14,6 +14,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BT = 128;                 // time tile
 constexpr int BKC = 32;                 // channels per staged chunk -> 96 K rows = 6 k-steps of 16
@@ -213,12 +215,19 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
       ptv[4] = p1.x; ptv[5] = p1.y; ptv[6] = p1.z; ptv[7] = p1.w;
     }
     if constexpr (X4) {
+      // written so that it lowers to 32 v_add_f32, 16 v_cvt_pk_bf16_f32 (channel pairs of one sample) and 16 v_and
+      // (zero padding) -- not the per-element convert + select + permute form (112 VALU).  (A v_pk_add_f32 form of the
+      // adds produced wrong even samples in lanes 48-63 on this toolchain; left scalar.)
+      const unsigned keep = tok[0] ? 0xffffffffu : 0u;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        bf16x8 pk;
+        u32x4 pk;
 #pragma unroll
-        for (int e = 0; e < 8; e++) pk[e] = (__bf16)(tok[0] ? xr[e * 4 + i] + ptv[e] : 0.f);
-        *reinterpret_cast<bf16x8 *>(dst + ((xcol + i) * XSTRIDE + xk) * 2) = pk;
+        for (int e2 = 0; e2 < 4; e2++)
+          pk[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                                                    f32x2{xr[(2 * e2) * 4 + i] + ptv[2 * e2],
+                                                          xr[(2 * e2 + 1) * 4 + i] + ptv[2 * e2 + 1]}, bf16x2)) & keep;
+        *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XSTRIDE + xk) * 2) = pk;
       }
     } else {
 #pragma unroll
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
       bf16x4 pk;
 #pragma unroll
       for (int e = 0; e < 4; e++)
-        pk[e] = (__bf16)((ablate & 2) ? acc[0][ct][4 * qq + e] : gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]));
+        pk[e] = (__bf16)gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
       *reinterpret_cast<bf16x4 *>(lds + GOFF + ((32 * ct + j) * GSTRIDE + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
     }
     __builtin_amdgcn_sched_barrier(0);
