@@ -62,11 +62,12 @@ def cpu_baseline(budget_s: float = 25.0):
                       f"5-step metric"}
 
 
-def pmc_traffic(B):
+def pmc_traffic(B, precision="f32"):
     """HBM-side bytes per residual-block launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 calibration, + WRITE_SIZE), scaled from the 512-clip launch it was measured on; None if absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+        name = "r1_pmc_traffic.json" if precision == "f32" else "r1_bf16_pmc_traffic.json"
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return round(d["traffic_bytes_per_launch"] * B / 512.0)
     except Exception:
         return None
@@ -176,7 +177,7 @@ def main():
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "resblock_bf16_kernel<256>", "achieved": round(gbs, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic(B, "bf16"),
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
         roof.update({"launches": int(launches.value), "avg_launch_ms": round(k_ms, 4),
                      "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,

@@ -11,7 +11,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_LEVEL_LDS SQ_INSTS_LDS" \
            "SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$repo/$out/p$i" -o r -- python3 "$repo/tools/run_resblock.py" 256 $prec 2 > "$repo/$out/p$i.log" 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$repo/$out/p$i" -o r -- python3 "$repo/tools/run_resblock.py" ${3:-256} $prec 2 > "$repo/$out/p$i.log" 2>&1
 done
 python3 - "$repo/$out" <<'PY'
 import sys, glob, csv, collections
