@@ -64,12 +64,13 @@ static int check_cfg(const ap_config &c) {
     set_error("config: invalid layer/embedding/schedule sizes");
     return -22;
   }
-  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16) {
-    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16)", c.precision);
+  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16 && c.precision != AP_PREC_F32_SPLIT) {
+    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16, AP_PREC_F32_SPLIT)", c.precision);
     return -22;
   }
-  if (c.precision == AP_PREC_BF16 && c.res_channels != 256) {
-    set_error("config: AP_PREC_BF16 is built for res_channels = 256 only (got %d)", c.res_channels);
+  if (c.precision != AP_PREC_F32 && c.res_channels != 256) {
+    set_error("config: AP_PREC_BF16 / AP_PREC_F32_SPLIT are built for res_channels = 256 only (got %d)",
+              c.res_channels);
     return -22;
   }
   return 0;
@@ -99,6 +100,8 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->slab = nullptr;
   c->slab_bf = nullptr;
   c->w1p_bf = c->w2p_bf = nullptr;
+  c->slab_s = nullptr;
+  c->w1p_s = c->w2p_s = nullptr;
   c->profile = false;
   c->ev_used = 0;
   const int T = cfg->T;
@@ -129,6 +132,7 @@ extern "C" int ap_ctx_destroy(ap_ctx *ctx) {
   if (!ctx) return 0;
   if (ctx->slab) (void)hipFree(ctx->slab);
   if (ctx->slab_bf) (void)hipFree(ctx->slab_bf);
+  if (ctx->slab_s) (void)hipFree(ctx->slab_s);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
@@ -233,6 +237,16 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
       ctx->w2p_bf = (char *)ctx->slab_bf + n1 * 2;
     }
     rc = launch_pack_bf16(ctx, st);
+    if (rc) return rc;
+  }
+  if (c.precision == AP_PREC_F32_SPLIT) {
+    const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
+    if (!ctx->slab_s) {
+      AP_HIP(hipMalloc(&ctx->slab_s, (n1 + n2) * 3 * 2));
+      ctx->w1p_s = ctx->slab_s;
+      ctx->w2p_s = (char *)ctx->slab_s + n1 * 3 * 2;
+    }
+    rc = launch_pack_split(ctx, st);
     if (rc) return rc;
   }
   AP_HIP(hipStreamSynchronize(st));

@@ -62,6 +62,8 @@ struct ap_ctx {
   float *w1p, *w2p, *wf1p;  // packed fp32 MFMA A-operand images
   void *w1p_bf, *w2p_bf;    // packed bf16 images (AP_PREC_BF16), own allocation
   void *slab_bf;
+  void *w1p_s, *w2p_s;      // 3-way bf16-split images (AP_PREC_F32_SPLIT), own allocation
+  void *slab_s;
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
   bool profile;
@@ -91,6 +93,9 @@ int launch_affine_noise(const float *x, float *out, float ca, float cs, const fl
 int launch_pack_bf16(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st);
+int launch_pack_split(ap_ctx *ctx, hipStream_t st);
+int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
+                          int accumulate, int B, int L, hipStream_t st);
 int launch_m5(ap_m5 *m, const float *x, float *logprobs, int B, int L, hipStream_t st);
 int launch_m5_fold(ap_m5 *m, const float *blob, float bn_eps, hipStream_t st);
 }  // namespace ap

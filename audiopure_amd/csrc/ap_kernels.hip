@@ -495,7 +495,7 @@ static int g_ablate = 0;   // timing-only ablation mask (ap_debug_ablate); 0 in 
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                     int accumulate, int B, int L, hipStream_t st) {
-  if (ctx->cfg.precision == AP_PREC_BF16 && !g_force_f32) {
+  if (ctx->cfg.precision != AP_PREC_F32 && !g_force_f32) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profile) {
       if (ctx->ev_used + 2 > ctx->ev.size())
@@ -509,7 +509,9 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
       ctx->ev_used += 2;
       AP_HIP(hipEventRecord(e0, st));
     }
-    int rc = launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+    int rc = ctx->cfg.precision == AP_PREC_BF16
+                 ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st)
+                 : launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
     if (e1) AP_HIP(hipEventRecord(e1, st));
     return rc;
   }

@@ -147,9 +147,12 @@ class WaveNet_Speech_Commands(nn.Module):
 
     # ---- native plumbing ------------------------------------------------------------------
     def set_precision(self, mode: str):
-        """"f32": exact fp32 MFMA (default, the reference's arithmetic).  "bf16": bf16 MFMA operands, fp32 accumulate
-        and storage (BASELINE configs[3]); only for res_channels = 256."""
-        prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16}[mode]
+        """"f32": exact fp32 MFMA (default, the reference's arithmetic).  "f32s": fp32 operands split exactly into three
+        bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results, ~2x faster.
+        "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  The last two need
+        res_channels = 256."""
+        prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
+                "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT}[mode]
         if prec != self._precision:
             self._precision = prec
             self._engine = None

@@ -41,7 +41,10 @@ typedef struct ap_m5 ap_m5;
 /* arithmetic mode of the two residual-block GEMMs */
 enum {
   AP_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
-  AP_PREC_BF16 = 1   /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM */
+  AP_PREC_BF16 = 1,  /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM */
+  AP_PREC_F32_SPLIT = 2  /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
+                            each product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-class results (dropped
+                            terms < 2^-23 of a product) at 6/16 of the fp32 matrix instruction's time; C = 256 */
 };
 
 /* configs/config.json "wavenet_config" + "diffusion_config" (reference: configs/config.json:2-17) */

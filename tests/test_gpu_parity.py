@@ -355,6 +355,64 @@ def test_bf16_full_chain_close_to_fp32_reference(golden, dev, dh):
 
 
 # ---- direct C-ABI entry points, chunking, graph capture ---------------------------------------------------------
+# ---- AP_PREC_F32_SPLIT: fp32 operands as three bf16 parts, six partial products on the bf16 MFMA ------------------
+@pytest.mark.parametrize("L,layer", [(1500, 2), (2048, 10), (4133, 11), (130, 3), (16000, 0)])
+def test_split_resblock_matches_oracle_at_the_fp32_tolerance(dev, L, layer):
+    """Same inputs and the SAME tolerance (5e-6 of max) as test_resblock_matches_oracle holds the exact fp32 MFMA
+    kernel to; and the two kernels agree with each other to fp32 rounding noise."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    C_ = 256
+    cfg = synth.mini_wavenet_config(C_, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    B = 2
+    h = torch.from_numpy(synth.uniform(f"h/{C_}/{L}", (B, C_, L), 1, -1.5, 1.5))
+    skip0 = torch.from_numpy(synth.uniform(f"s/{C_}/{L}", (B, C_, L), 1, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    with torch.no_grad():
+        p = f"residual_layer.residual_blocks.{layer}"
+        part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        h_ref, s_ref = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb)
+    hd = h.to(dev)
+    pt = part_t.to(dev).contiguous()
+    outs = {}
+    for mode in ("f32", "f32s"):
+        net.set_precision(mode)
+        eng = net.engine()
+        sk = skip0.to(dev).clone()
+        hout = torch.empty_like(hd)
+        N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
+        assert rel_err(hout.cpu().numpy(), h_ref.numpy()) < 5e-6, mode
+        assert rel_err(sk.cpu().numpy(), (skip0 + s_ref).numpy()) < 5e-6, mode
+        sk2 = torch.full_like(sk, 7.0)
+        N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk2), 0, B, L, N.stream()))
+        assert rel_err(sk2.cpu().numpy(), s_ref.numpy()) < 5e-6, mode
+        outs[mode] = (hout.cpu().numpy(), sk2.cpu().numpy())
+    assert rel_err(outs["f32s"][0], outs["f32"][0]) < 2e-6
+    assert rel_err(outs["f32s"][1], outs["f32"][1]) < 2e-6
+
+
+def test_split_full_chain_matches_reference_golden_at_the_fp32_tolerance(golden, dev, dh):
+    """Whole shipped-config DDPM n=5 + one-shot denoise in split mode vs the reference's fp32 golden vectors, at the
+    tolerances the exact-fp32 tests use (TOL_CHAIN / TOL_EVAL)."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, _ = _net(cfg, dev)
+    net.set_precision("f32s")
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
+    with torch.no_grad():
+        eps = net((x0, 4.0 * torch.ones(2, 1, device=dev)))
+    assert rel_err(eps.cpu().numpy(), golden["full/eps_t4"]) < TOL_EVAL
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=5)
+    dw.set_noise_source([torch.from_numpy(synth.noise(d, 2, 16000, seed=1234)) for d in range(5)])
+    xp = dw(x0)
+    assert rel_err(xp.cpu().numpy(), golden["full/ddpm_n5/x"]) < TOL_CHAIN
+    assert rel_err(dw.one_shot_denoise(x0).cpu().numpy(), golden["full/one_shot_t5"] if "full/one_shot_t5" in golden
+                   else DiffWave(model=net.set_precision("f32"), diffusion_hyperparams=dh,
+                                 reverse_timestep=5).one_shot_denoise(x0).cpu().numpy()) < TOL_EVAL
+
+
 def test_c_entry_points_match_python_chains(mini, dh, dev):
     """ap_purify_ddpm / ap_purify_sde / ap_one_shot_denoise (coefficients computed inside the library from the installed
     tables) give the same result as the chains the Python classes build with ap_purify_chain."""
