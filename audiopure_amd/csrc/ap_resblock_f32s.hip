@@ -44,6 +44,25 @@ __device__ __forceinline__ void split3(float x, __bf16 (&p)[3]) {
   p[2] = (__bf16)r2;
 }
 
+// four values at once, written so the conversions lower to v_cvt_pk_bf16_f32 (two per instruction) and the
+// widenings to one shift / mask: 11 VALU per pair instead of ~20
+typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3x4(const float (&x)[4], u32x2s (&out)[3]) {
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++) {
+    float v0 = x[2 * pr], v1 = x[2 * pr + 1];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+      const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v0, v1}, bf16x2));
+      out[s][pr] = pk;
+      if (s < 2) {
+        v0 -= __builtin_bit_cast(float, pk << 16);
+        v1 -= __builtin_bit_cast(float, pk & 0xffff0000u);
+      }
+    }
+  }
+}
+
 // same compensated exp and gate as the fp32 kernel (ap_kernels.hip) -- the gate is not where the two modes differ
 __device__ __forceinline__ float exp_acc_s(float x) {
   const float L2E_HI = 1.44269502162933349609375f;
@@ -126,11 +145,12 @@ int launch_pack_split(ap_ctx *ctx, hipStream_t st) {
 // the six partial products kept, as (weight split, activation split)
 #define AP_SPLIT_TERMS(F) F(0, 0) F(0, 1) F(1, 0) F(0, 2) F(2, 0) F(1, 1)
 
-template <int C, bool E4>
+template <int C, bool E4, bool TRACE>
 __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const __bf16 *__restrict__ w1p, const float *__restrict__ b1, const __bf16 *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk) {
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk,
+    unsigned long long *__restrict__ trace) {
   constexpr int NW = C / 32, NT = NW * 64, NCH = C / BKC;
   static_assert(NT == 512 && NCH % 2 == 0, "built for C = 256 (8 waves)");
   constexpr int GS = C + 8;                                    // bf16 per column row of a g image (528 B)
@@ -149,6 +169,12 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
+  auto mark = [&](int i) {                                     // phase stamps (tools/trace_resblock_bf16.py); trace builds only
+    if constexpr (TRACE) {
+      if (lane == 0) trace[((size_t)blockIdx.x * NW + wave) * 16 + i] = __builtin_readcyclecounter();
+    }
+  };
+  mark(0);
   int logical;                                                 // XCD-local tile order (see ap_resblock_bf16.hip)
   {
     const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
@@ -206,17 +232,14 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
     const float pte[4] = {pv.x, pv.y, pv.z, pv.w};
 #pragma unroll
     for (int tap = 0; tap < 3; tap++) {
-      bf16x4 pk[3];
+      float u[4];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        __bf16 p[3];
-        split3(tok[tap] ? xr[tap][e] + pte[e] : 0.f, p);
-#pragma unroll
-        for (int s = 0; s < 3; s++) pk[s][e] = p[s];
-      }
+      for (int e = 0; e < 4; e++) u[e] = tok[tap] ? xr[tap][e] + pte[e] : 0.f;
+      u32x2s pk[3];
+      split3x4(u, pk);
 #pragma unroll
       for (int s = 0; s < 3; s++)
-        *reinterpret_cast<bf16x4 *>(dst + s * XIMG + (col * XS + tap * BKC + q4) * 2) = pk[s];
+        *reinterpret_cast<u32x2s *>(dst + s * XIMG + (col * XS + tap * BKC + q4) * 2) = pk[s];
     }
   };
 
@@ -224,6 +247,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
   __syncthreads();                                              // part_t visible
   store_chunk(lds, 0);
   __syncthreads();
+  mark(1);
 
   // ---- GEMM1: 48 k-steps (16 chunks x 3 taps), 48 MFMAs each: 2 row tiles x 4 column tiles x 6 partial products.
   // Weight fragments (2 row tiles x 3 splits = 24 VGPRs per k-step) stream from L2 one k-step ahead, ping-pong.
@@ -234,12 +258,25 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
       for (int s = 0; s < 3; s++) a[rt][s] = __builtin_bit_cast(bf16x8, base[(rt * 3 + s) * 64]);
   };
   const int rdoff = (j * XS + 8 * hh) * 2;                      // this lane's B-fragment byte offset inside an X image
-  auto mma_k = [&](const bf16x8(&a)[2][3], const unsigned char *xb) {   // xb: buffer + rdoff + tap * 32
+  // bpre holds the first column tile's three B fragments of the k-step about to run; inside a chunk the next k-step's
+  // are fetched under this one's last MFMAs, so a k-step boundary does not wait on LDS (across the chunk barrier the
+  // other buffer is not valid yet: NEXT = false there and the caller refills bpre after the barrier)
+  bf16x8 bpre[3];
+  auto read_b = [&](bf16x8(&bv)[3], const unsigned char *xb, int ct) {
+#pragma unroll
+    for (int s = 0; s < 3; s++) bv[s] = *reinterpret_cast<const bf16x8 *>(xb + s * XIMG + (32 * ct) * (XS * 2));
+  };
+  auto mma_k = [&](const bf16x8(&a)[2][3], const unsigned char *xb, auto NEXT) {   // xb: buffer + rdoff + tap * 32
 #pragma unroll
     for (int ct = 0; ct < 4; ct++) {
       bf16x8 bv[3];
+      if (ct == 0) {
 #pragma unroll
-      for (int s = 0; s < 3; s++) bv[s] = *reinterpret_cast<const bf16x8 *>(xb + s * XIMG + (32 * ct) * (XS * 2));
+        for (int s = 0; s < 3; s++) bv[s] = bpre[s];
+      } else {
+        read_b(bv, xb, ct);
+      }
+      if (ct == 3 && decltype(NEXT)::value) read_b(bpre, xb + 32, 0);
 #pragma unroll
       for (int rt = 0; rt < 2; rt++) {
 #define AP_T(i, jx) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt][i], bv[jx], acc[rt][ct], 0, 0, 0);
@@ -248,46 +285,68 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
       }
     }
   };
+  using YES = std::true_type;
+  using NO = std::false_type;
   const u32x4 *ap = reinterpret_cast<const u32x4 *>(w1p) + (size_t)wave * NCH * 3 * 6 * 64 + lane;
   auto aset = [&](int kk) { return ap + (size_t)(kk < NCH * 3 ? kk : NCH * 3 - 1) * 6 * 64; };
+  // the next chunk's FiLM add / split / pack (VALU) goes into the gaps of the third k-step's 48 MFMAs
+  auto pack_between_mfmas = [&]() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 48; i++) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      if (i % 12 == 1 && i < 36) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+    }
+  };
   bf16x8 a0[2][3], a1[2][3];
   load_a(a0, aset(0));
 #pragma unroll 1
   for (int it = 0; it < NCH / 2; it++) {
     const int c0 = 2 * it, kk = 6 * it;
     const unsigned char *x0 = lds + rdoff, *x1 = lds + XBUF + rdoff;
+    read_b(bpre, x0, 0);
     // vmcnt retires in issue order: the next weight set is requested before the (HBM-latency) X loads
     load_a(a1, aset(kk + 1));
     issue_loads(c0 + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_k(a0, x0);
+    mma_k(a0, x0, YES{});
     __builtin_amdgcn_sched_barrier(0);
+    if (it == 4) mark(10);
     load_a(a0, aset(kk + 2));
     __builtin_amdgcn_sched_barrier(0);
-    mma_k(a1, x0 + 32);
+    mma_k(a1, x0 + 32, YES{});
     __builtin_amdgcn_sched_barrier(0);
     load_a(a1, aset(kk + 3));
     __builtin_amdgcn_sched_barrier(0);
-    mma_k(a0, x0 + 64);
-    __builtin_amdgcn_sched_barrier(0);
+    mma_k(a0, x0 + 64, NO{});
     store_chunk(lds + XBUF, c0 + 1);
+    pack_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    if (it == 4) mark(12);
     __syncthreads();
+    if (it == 3) mark(3);
+    if (it == 4) mark(13);
+    read_b(bpre, x1, 0);
     load_a(a0, aset(kk + 4));
     issue_loads(c0 + 2 < NCH ? c0 + 2 : NCH - 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_k(a1, x1);
+    mma_k(a1, x1, YES{});
     __builtin_amdgcn_sched_barrier(0);
     load_a(a1, aset(kk + 5));
     __builtin_amdgcn_sched_barrier(0);
-    mma_k(a0, x1 + 32);
+    mma_k(a0, x1 + 32, YES{});
     __builtin_amdgcn_sched_barrier(0);
     load_a(a0, aset(kk + 6));
     __builtin_amdgcn_sched_barrier(0);
-    mma_k(a1, x1 + 64);
-    __builtin_amdgcn_sched_barrier(0);
+    mma_k(a1, x1 + 64, NO{});
     store_chunk(lds, c0 + 2 < NCH ? c0 + 2 : NCH - 1);          // after the last chunk: a harmless re-store
+    pack_between_mfmas();
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    if (it == 0) mark(2);
   }
+  mark(4);
 
   // ---- per 64-column half: gate (WaveNet.py:90) -> three g images [col][channel]; GEMM2 in two passes of 32 rows x 64
   // columns (pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip; WaveNet.py:93-97, :133).
@@ -309,21 +368,19 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
       const int ct = 2 * h + c2;
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
-        bf16x4 pk[3];
+        float gv[4];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          __bf16 p[3];
-          split3(gate_s(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]), p);
-#pragma unroll
-          for (int s = 0; s < 3; s++) pk[s][e] = p[s];
-        }
+        for (int e = 0; e < 4; e++) gv[e] = gate_s(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
+        u32x2s pk[3];
+        split3x4(gv, pk);
 #pragma unroll
         for (int s = 0; s < 3; s++)
-          *reinterpret_cast<bf16x4 *>(lds + s * GIMG + ((32 * c2 + j) * GS + 32 * wave + 8 * qq + 4 * hh) * 2) = pk[s];
+          *reinterpret_cast<u32x2s *>(lds + s * GIMG + ((32 * c2 + j) * GS + 32 * wave + 8 * qq + 4 * hh) * 2) = pk[s];
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    mark(h == 0 ? 5 : 8);
 
     unsigned evoff[2];
 #pragma unroll
@@ -438,13 +495,18 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
       }
     };
     gemm2_pass(std::integral_constant<int, 0>{});
+    mark(h == 0 ? 6 : 9);
     __builtin_amdgcn_sched_barrier(0);
     gemm2_pass(std::integral_constant<int, 1>{});
   };
   half(std::integral_constant<int, 0>{});
+  mark(7);
   __syncthreads();                                              // every wave is done reading half 0's g images
   half(std::integral_constant<int, 1>{});
+  mark(14);
 }
+
+extern unsigned long long *g_trace_bf16;
 
 int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st) {
@@ -460,12 +522,15 @@ int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float 
   const __bf16 *w2p = (const __bf16 *)ctx->w2p_s + (size_t)layer * (C + S) * C * 3;
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
-  if (L % 4 == 0 && L >= 4)
-    resblock_f32s_kernel<256, true><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
-                                                                   accumulate, ntiles, nblk);
+  if (L % 4 == 0 && L >= 4 && g_trace_bf16)
+    resblock_f32s_kernel<256, true, true><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
+                                                                         accumulate, ntiles, nblk, g_trace_bf16);
+  else if (L % 4 == 0 && L >= 4)
+    resblock_f32s_kernel<256, true, false><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
+                                                                          accumulate, ntiles, nblk, nullptr);
   else
-    resblock_f32s_kernel<256, false><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
-                                                                    accumulate, ntiles, nblk);
+    resblock_f32s_kernel<256, false, false><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
+                                                                           accumulate, ntiles, nblk, nullptr);
   AP_HIP(hipGetLastError());
   return 0;
 }

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
     ap.add_argument("--reverse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-modes", action="store_true", help="time only --precision (skip the f32s / bf16 legs)")
     ap.add_argument("--precision", choices=["f32", "f32s", "bf16"], default="f32",
                     help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
@@ -113,72 +114,73 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B, L, n = args.batch, 16000, args.reverse_steps
+    import numpy as np
+    import types
     cfg = dict(synth.FULL_WAVENET_CONFIG)
     net = WaveNet_Speech_Commands(**cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(cfg, 0).items()})
     net = net.to(dev)
-    net.set_precision(args.precision)
-    dw = DiffWave(model=net, diffusion_hyperparams=calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG),
-                  reverse_timestep=n)
-    dw.set_noise_source(("philox", 1234, rank * B))              # global utterance index = rank*B + b
     m5 = M5(n_input=1, n_output=10)
-    import numpy as np
     m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
     m5 = m5.to(dev).eval()
-    defender = dw
-    if args.sampler == "sde":                                    # BASELINE configs[3]: RevDiffWave VP-SDE Euler chain
-        import types
-        from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
-        defender = RevDiffWave.from_model(dw, types.SimpleNamespace(
-            t=n, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1))
-    system = AcousticSystem(classifier=m5, transform=None, defender=defender, defense_type="wave")
     # synthetic 0.5*U(-1,1) clips, generated on device (resident in HBM before timing)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     x0 = (torch.rand((B, 1, L), device=dev, generator=g) - 0.5).contiguous()
-    eng = net.engine()
-    eng.max_chunk = B
-
-    def step():
-        lp = system(x0, True)
-        if use_dist:
-            return all_gather_scores(lp, world * B)         # the path's only collective: [B,10] scores / rank
-        return lp
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        N.check(eng.lib.ap_profile_enable(eng.ctx, 1))
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            lp = step()
-        fence()
-        elapsed = time.perf_counter() - t0
-    tot_ms, launches = C.c_double(), C.c_int64()
-    N.check(eng.lib.ap_profile_read(eng.ctx, C.byref(tot_ms), C.byref(launches)))
-    N.check(eng.lib.ap_profile_enable(eng.ctx, 0))
-    assert torch.isfinite(lp).all()
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_mode(precision, steps, warmup):
+        """W untimed + K timed passes of the hot path in one arithmetic mode -> (elapsed s, kernel ms, launches)."""
+        net.set_precision(precision)
+        dw = DiffWave(model=net, diffusion_hyperparams=calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG),
+                      reverse_timestep=n)
+        dw.set_noise_source(("philox", 1234, rank * B))          # global utterance index = rank*B + b
+        defender = dw
+        if args.sampler == "sde":                                # BASELINE configs[3]: RevDiffWave VP-SDE Euler chain
+            from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+            defender = RevDiffWave.from_model(dw, types.SimpleNamespace(
+                t=n, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1))
+        system = AcousticSystem(classifier=m5, transform=None, defender=defender, defense_type="wave")
+        eng = net.engine()
+        eng.max_chunk = B
 
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = world * B * args.steps / elapsed
-        k_ms = tot_ms.value / max(launches.value, 1)
+        def step():
+            lp = system(x0, True)                               # purify (n reverse steps) + classify, all in HIP
+            if use_dist:
+                return all_gather_scores(lp, world * B)         # the path's only collective: [B,10] scores / rank
+            return lp
+
+        with torch.no_grad():
+            for _ in range(warmup):
+                step()
+            N.check(eng.lib.ap_profile_enable(eng.ctx, 1))
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                lp = step()
+            fence()
+            elapsed = time.perf_counter() - t0
+        tot_ms, launches = C.c_double(), C.c_int64()
+        N.check(eng.lib.ap_profile_read(eng.ctx, C.byref(tot_ms), C.byref(launches)))
+        N.check(eng.lib.ap_profile_enable(eng.ctx, 0))
+        assert torch.isfinite(lp).all()
+        if use_dist:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, tot_ms.value / max(launches.value, 1), int(launches.value)
+
+    def roofline(precision, k_ms, launches):
         achieved = FLOP_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e12
-        if args.precision == "f32":
+        if precision == "f32":
             roof = {"bound": "mfma", "kernel": "resblock_f32_kernel<256,64>", "achieved": round(achieved, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                     "traffic": pmc_traffic(B)}
-        elif args.precision == "f32s":
+        elif precision == "f32s":
             # fp32 operands as three bf16 parts, 6 bf16 MFMAs per fp32 MFMA-equivalent: the ceiling for ALGORITHMIC
             # flops is the dense bf16 MFMA peak / 6
             peak = 2500.0 / 6.0
@@ -193,10 +195,33 @@ def main():
             roof = {"bound": "hbm", "kernel": "resblock_bf16_kernel<256>", "achieved": round(gbs, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic(B, "bf16"),
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
-        roof.update({"launches": int(launches.value), "avg_launch_ms": round(k_ms, 4),
+        roof.update({"launches": launches, "avg_launch_ms": round(k_ms, 4),
                      "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,
                      "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
                      "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)})
+        return roof
+
+    elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
+    # the other arithmetic modes of the same path, measured in the same run (N = 1 only: they are extra evidence,
+    # not the headline): same inputs, same chain, same timing brackets
+    others = {}
+    if world == 1 and not args.no_other_modes:
+        for prec in ("f32s", "bf16", "f32"):
+            if prec == args.precision:
+                continue
+            if prec == "f32" and args.precision != "f32":
+                e2, k2, l2 = run_mode(prec, 1, 0)
+                st = 1
+            else:
+                e2, k2, l2 = run_mode(prec, args.steps, args.warmup)
+                st = args.steps
+            others[prec] = {"arithmetic": PREC_NAME[prec], "value": round(B * st / e2, 3), "unit": "utterances/s",
+                            "steps": st, "ms_per_step": round(e2 * 1e3 / st, 3), "roofline": roofline(prec, k2, l2)}
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = world * B * args.steps / elapsed
+        roof = roofline(args.precision, k_ms, launches)
         out = {
             "metric": f"purified 1s@16kHz utterances/sec at {n} reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
@@ -209,6 +234,8 @@ def main():
                        "parallelism": f"utterance-sharded x{world}, logits all_gather"},
             "roofline": roof,
         }
+        if others:
+            out["other_modes"] = others
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

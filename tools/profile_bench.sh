@@ -4,11 +4,11 @@
 prec=${1:-f32}; out=${2:-gpurun_out/prof_$prec}
 repo=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$repo/$out"; cd /tmp; export TMPDIR=/tmp
-python3 "$repo/bench.py" --precision $prec > "$repo/$out/bench.json" 2> "$repo/$out/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/stats" -o r -- python3 "$repo/bench.py" --precision $prec --no-cpu-baseline > "$repo/$out/stats.log" 2>&1
+python3 "$repo/bench.py" --precision $prec --no-other-modes > "$repo/$out/bench.json" 2> "$repo/$out/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/stats" -o r -- python3 "$repo/bench.py" --precision $prec --no-cpu-baseline --no-other-modes > "$repo/$out/stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$repo/$out/pmc_$n" -o r -- python3 "$repo/bench.py" --precision $prec --steps 1 --warmup 0 --no-cpu-baseline > "$repo/$out/pmc_$n.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$repo/$out/pmc_$n" -o r -- python3 "$repo/bench.py" --precision $prec --steps 1 --warmup 0 --no-cpu-baseline --no-other-modes > "$repo/$out/pmc_$n.log" 2>&1
 done
 python3 - "$repo/$out" <<'PY'
 import sys, glob, csv, collections, json
