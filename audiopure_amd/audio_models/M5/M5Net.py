@@ -73,5 +73,7 @@ class M5(nn.Module):
         h = self._handle()
         x = x.detach().float().contiguous()
         out = torch.empty((x.shape[0], self.fc1.out_features), device=x.device, dtype=torch.float32)
+        if x.shape[0] == 0:                                      # empty batch: empty scores, like the torch modules
+            return out
         N.check(N.lib().ap_m5_fwd(h, N.ptr(x), N.ptr(out), x.shape[0], x.shape[2], N.stream()), "ap_m5_fwd")
         return out

@@ -307,6 +307,22 @@ def test_errors_are_loud(mini, dh, dev):
     assert out.shape == x.shape and out.is_cuda
 
 
+def test_empty_batch_flows_through_like_the_torch_modules(mini, dh, dev):
+    """The reference's modules map an empty batch to empty outputs; so does the boundary (no launch, no error)."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.audio_models.M5.M5Net import M5
+    from audiopure_amd.acoustic_system import AcousticSystem
+    cfg, net, _ = mini
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    m5 = M5(n_input=1, n_output=10)
+    m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
+    m5 = m5.to(dev).eval()
+    x = torch.empty((0, 1, 16000), device=dev)
+    assert dw(x).shape == (0, 1, 16000)
+    out = AcousticSystem(classifier=m5, transform=None, defender=dw, defense_type="wave")(x, True)
+    assert out.shape[0] == 0
+
+
 # ---- AP_PREC_BF16 (BASELINE configs[3]): bf16 MFMA operands, fp32 accumulate / storage -------------------------
 @pytest.mark.parametrize("L,layer", [(2048, 0), (1500, 5), (4133, 11), (130, 3)])
 def test_bf16_resblock_matches_bf16_emulating_oracle(dev, L, layer):
