@@ -348,7 +348,7 @@ class NativeConvNet(nn.Module):
                 continue
             w = W[st.p["wk"]]
             Cout, Cg, kh, kw = w.shape
-            wT = torch.empty(Cout * Cg * kh * kw, device=dev, dtype=torch.float32)
+            wT = torch.empty(lib.ap_conv2d_packed_elems(Cout, Cg, kh, kw, st.p["groups"]), device=dev, dtype=torch.float32)
             sc = W[st.p["sk"]].contiguous() if st.p["sk"] else None
             N.check(lib.ap_conv2d_pack(N.ptr(w.contiguous()), N.ptr(sc), N.ptr(wT), Cout, Cg, kh, kw, st.p["groups"], N.stream()),
                     "ap_conv2d_pack")

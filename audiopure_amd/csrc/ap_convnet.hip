@@ -221,6 +221,149 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
   }
 }
 
+// 128 x 128 tiles with the weights streamed (layers with Cin/g % 16 == 0, i.e. everything past a network's stem).
+// Two things bounded conv2d_f32_big_kernel at ~36 % of the MFMA peak: every K chunk each thread fetched, range-checked
+// and LDS-staged 8 weights and 8 gathered activations with per-element (ci, ky, kx) bookkeeping.  Here
+//  * K runs tap-major, k' = (ky kw + kx) Cg + ci, so a 16-row chunk is ONE tap over 16 consecutive channels: one
+//    range check and one base address per thread per chunk, elements HW apart;
+//  * the weights are pre-packed in the MFMA A-operand layout ([group][32-row tile][k'/8][lane][4]) and go L2 ->
+//    registers as dwordx4, one chunk ahead: no LDS, no stores, no bank traffic for them (LDS holds only the 16 KB
+//    double-buffered im2col tile, so more workgroups fit a CU).
+__global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag) {
+  constexpr int BN = 128, BK = 16;
+  __shared__ float Bs[2][BK][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, hh = lane >> 5;
+  const int Mg = a.Cout / a.groups, Cg = a.Cin / a.groups, KK = a.kh * a.kw, Kg = Cg * KK;
+  const int HoWo = a.Ho * a.Wo, N = a.B * HoWo;
+  const int g = blockIdx.z, m0 = blockIdx.y * 128, n0 = blockIdx.x * BN;
+  const int nl = tid & 127, kq = tid >> 7;             // element i of a thread: chunk row kq + 2 i, column nl
+  const int n = n0 + nl;
+  const bool nvalid = n < N;
+  const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const int HW = a.H * a.W;
+  const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg + kq) * HW;
+  const int MT = (Mg + 31) / 32, KQ = Kg / 8, CPT = Cg / BK;   // row tiles, k' quads per row tile, chunks per tap
+  const f32x4 *af[2];
+#pragma unroll
+  for (int x_ = 0; x_ < 2; x_++) {
+    const int mt = min((m0 >> 5) + 2 * wm + x_, MT - 1);       // a tile past the end re-reads the last one (never stored)
+    af[x_] = reinterpret_cast<const f32x4 *>(afrag) + ((size_t)g * MT + mt) * KQ * 64 + lane;
+  }
+  const int nchunk = KK * CPT;
+  float br[8];
+  auto load_b = [&](int c) {                                   // chunk c = (tap r, channels c0 .. c0+15)
+    const int r = c / CPT, c0 = (c - r * CPT) * BK;
+    const int ky = r / a.kw, kx = r - ky * a.kw;
+    const int iy = iy0 + ky, ix = ix0 + kx;
+    const bool ok = nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float v = p[(size_t)(2 * i) * HW];
+      br[i] = ok ? v : 0.f;
+    }
+  };
+  auto load_a = [&](f32x4(&aa)[2][2], int c) {
+#pragma unroll
+    for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) aa[x_][q] = af[x_][(size_t)(2 * c + q) * 64];
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) Bs[buf][kq + 2 * i][nl] = br[i];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+    for (int y_ = 0; y_ < 2; y_++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[x_][y_][r] = 0.f;
+  auto compute = [&](const f32x4(&aa)[2][2], int buf) {
+#pragma unroll
+    for (int s = 0; s < BK / 2; s++) {
+      float bf[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) bf[t] = Bs[buf][2 * s + hh][64 * wn + 32 * t + j];
+#pragma unroll
+      for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+        for (int y_ = 0; y_ < 2; y_++)
+          acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x_][s >> 2][s & 3], bf[y_], acc[x_][y_], 0, 0, 0);
+    }
+  };
+
+  f32x4 a0[2][2], a1[2][2];
+  load_a(a0, 0);
+  load_b(0);
+  store_b(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nchunk; c++) {
+    const int cn = c + 1 < nchunk ? c + 1 : c;                  // the last trip re-fetches its own chunk (unused)
+    load_b(cn);
+    load_a(a1, cn);
+    compute(a0, c & 1);
+    store_b((c + 1) & 1);
+#pragma unroll
+    for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+      for (int q = 0; q < 2; q++) a0[x_][q] = a1[x_][q];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int y_ = 0; y_ < 2; y_++) {
+    const int nn = n0 + 64 * wn + 32 * y_ + j;
+    if (nn < N) {
+      const int ob = nn / HoWo, op = nn % HoWo;
+#pragma unroll
+      for (int x_ = 0; x_ < 2; x_++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = m0 + 64 * wm + 32 * x_ + crowoff(r, hh);
+          if (m < Mg) {
+            const int co = g * Mg + m;
+            const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
+            float v = acc[x_][y_][r];
+            if (a.bias) v += a.bias[co];
+            if (a.res) v += a.res[off];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[off] = v;
+          }
+        }
+    }
+  }
+}
+
+// w [Cout][Cin/g][kh][kw] (* scale) -> A-operand fragments of v_mfma_f32_32x32x2_f32 in tap-major K order:
+// [group][row tile MT][k'/8][lane 64][4], element e of quad q = k' pair 4q + e, lane = (row i, half h): k' = 2 pair + h
+__global__ void conv_pack_frag_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                      float *__restrict__ out, int Cout, int Cg, int KK, int groups) {
+  const int Mg = Cout / groups, MT = (Mg + 31) / 32, Kg = Cg * KK, KQ = Kg / 8;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)groups * MT * KQ * 256;
+  if (idx >= total) return;
+  const int e = idx & 3, lane = (idx >> 2) & 63;
+  size_t rest = idx >> 8;
+  const int q = rest % KQ; rest /= KQ;
+  const int mt = rest % MT, g = rest / MT;
+  const int i = lane & 31, h = lane >> 5;
+  const int kp = 2 * (4 * q + e) + h;                           // k' = r Cg + ci
+  const int r = kp / Cg, ci = kp - r * Cg;
+  const int m = 32 * mt + i;
+  float v = 0.f;
+  if (m < Mg) {
+    const int co = g * Mg + m;
+    v = w[((size_t)co * Cg + ci) * KK + r];
+    if (scale) v *= scale[co];
+  }
+  out[idx] = v;
+}
+
 // w [Cout][Cin/g][kh][kw] (* per-output-channel scale) -> wT [groups][Kg][Mg]
 __global__ void conv_pack_kernel(const float *__restrict__ w, const float *__restrict__ scale, float *__restrict__ wT,
                                  int Cout, int Kg, int groups) {
@@ -304,12 +447,39 @@ __global__ void pool2d_kernel(const float *__restrict__ x, float *__restrict__ y
 
 using namespace ap;
 
+static int g_conv_no_frag = 0;     // ap_debug_conv_path(1): timing A/B against the LDS-staged 128 x 128 kernel
+static long long g_conv_frag_min_tiles = 256;   // one 128 x 128 tile per CU is enough for this kernel (swept: 512 / 256 / 128 / 64)
+extern "C" int ap_debug_conv_path(int no_frag) {
+  if (no_frag >= 16) g_conv_frag_min_tiles = no_frag;   // >= 16: set the tile-count threshold of the streamed-weight kernel
+  else g_conv_no_frag = no_frag;
+  return 0;
+}
+
+// layers the streamed-weight kernel serves carry a second image behind the first
+static bool conv_has_frag(int Cout, int Cin_g, int groups) { return Cin_g % 16 == 0 && Cout / groups >= 128; }
+static size_t conv_frag_elems(int Cout, int Cin_g, int kh, int kw, int groups) {
+  const int Mg = Cout / groups;
+  return (size_t)groups * ((Mg + 31) / 32) * 32 * Cin_g * kh * kw;
+}
+
+extern "C" size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups) {
+  if (Cout < 1 || Cin_g < 1 || kh < 1 || kw < 1 || groups < 1 || Cout % groups) return 0;
+  size_t n = (size_t)Cout * Cin_g * kh * kw;
+  if (conv_has_frag(Cout, Cin_g, groups)) n += conv_frag_elems(Cout, Cin_g, kh, kw, groups);
+  return n;
+}
+
 extern "C" int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw,
                               int groups, void *stream) {
   if (!w || !wT || Cout < 1 || Cin_g < 1 || groups < 1 || Cout % groups) { set_error("ap_conv2d_pack: bad argument"); return -22; }
   const int Kg = Cin_g * kh * kw;
   size_t n = (size_t)Cout * Kg;
   conv_pack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, scale, wT, Cout, Kg, groups);
+  if (conv_has_frag(Cout, Cin_g, groups)) {
+    const size_t nf = conv_frag_elems(Cout, Cin_g, kh, kw, groups);
+    conv_pack_frag_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, scale, wT + n, Cout, Cin_g,
+                                                                                       kh * kw, groups);
+  }
   AP_HIP(hipGetLastError());
   return 0;
 }
@@ -332,7 +502,12 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   const long long N = (long long)B * a.Ho * a.Wo;
   const int Mg = Cout / groups;
   // the 128 x 128 tile needs enough workgroups to fill 256 CUs; otherwise 4x as many 64 x 64 tiles win
-  if (Mg >= 128 && kh <= 3 && kw <= 3 && ((N + 127) / 128) * ((Mg + 127) / 128) * (long long)groups >= 512) {
+  const long long tiles128 = ((N + 127) / 128) * ((Mg + 127) / 128) * (long long)groups;
+  const bool many = tiles128 >= 512;
+  if (tiles128 >= g_conv_frag_min_tiles && conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
+    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+    conv2d_f32_big2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, wT + (size_t)Cout * (Cin / groups) * kh * kw);
+  } else if (Mg >= 128 && kh <= 3 && kw <= 3 && many) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
     conv2d_f32_big_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   } else {

@@ -114,7 +114,7 @@ class UNetModel(nn.Module):
                 cout = w.shape[0]
                 cin_g = w.shape[1]
                 kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
-                wT = torch.empty(w.numel(), device=dev, dtype=torch.float32)
+                wT = torch.empty(lib.ap_conv2d_packed_elems(cout, cin_g, kh, kw, 1), device=dev, dtype=torch.float32)
                 N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), cout, cin_g, kh, kw, 1, N.stream()), "ap_conv2d_pack")
                 packed[m] = (wT, m.bias.detach().float().contiguous() if m.bias is not None else None, cout, kh, kw,
                              (m.stride[0] if hasattr(m, "stride") else 1), (m.padding[0] if hasattr(m, "padding") else 0))

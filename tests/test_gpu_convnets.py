@@ -59,14 +59,18 @@ def test_conv2d_primitive_edge_shapes(dev):
     import torch.nn.functional as F
     from audiopure_amd import _native as N
     lib = N.lib()
+    # the last three reach the 128 x 128 kernels (>= 512 tiles): streamed-weight path incl. ragged M / N, groups,
+    # stride 2, 1x1, and (Cin/g = 24) the LDS-staged one
     for (B, Cin, H, Cout, k, s, p, g) in [(3, 8, 9, 12, 3, 1, 1, 1), (2, 16, 16, 40, 3, 2, 1, 4), (5, 33, 7, 70, 1, 1, 0, 1),
-                                          (1, 64, 4, 64, 3, 1, 1, 8), (4, 1, 32, 64, 3, 1, 1, 1)]:
+                                          (1, 64, 4, 64, 3, 1, 1, 8), (4, 1, 32, 64, 3, 1, 1, 1),
+                                          (33, 32, 32, 200, 3, 1, 1, 1), (70, 64, 31, 272, 3, 2, 1, 2),
+                                          (40, 48, 30, 160, 1, 1, 0, 1), (36, 24, 32, 136, 3, 1, 1, 1)]:
         x = torch.from_numpy(synth.uniform(f"cx{Cin}{H}", (B, Cin, H, H), 1))
         w = torch.from_numpy(synth.uniform(f"cw{Cin}{Cout}", (Cout, Cin // g, k, k), 1))
         b = torch.from_numpy(synth.uniform(f"cb{Cout}", (Cout,), 1))
         ref = F.relu(F.conv2d(x, w, b, stride=s, padding=p, groups=g))
         xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
-        wT = torch.empty(w.numel(), device=dev)
+        wT = torch.empty(lib.ap_conv2d_packed_elems(Cout, Cin // g, k, k, g), device=dev)
         N.check(lib.ap_conv2d_pack(N.ptr(wd), None, N.ptr(wT), Cout, Cin // g, k, k, g, N.stream()))
         out = torch.empty(ref.shape, device=dev)
         N.check(lib.ap_conv2d_fwd(N.ptr(xd), N.ptr(wT), N.ptr(bd), None, N.ptr(out), B, Cin, H, H, Cout, k, k, s, p, g, 1,

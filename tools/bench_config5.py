@@ -9,6 +9,9 @@ from audiopure_amd.diffusion_models.improved_diffusion_unet import create_model,
 from audiopure_amd.diffusion_models.improved_diffusion_sde import RevImprovedDiffusion
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+if len(sys.argv) > 2:                                  # A/B switch of the conv dispatch (ap_debug_conv_path)
+    from audiopure_amd import _native as N
+    N.lib().ap_debug_conv_path(int(sys.argv[2]))
 unet = synth_init(create_model(**model_and_diffusion_defaults()), 0).to(dev)
 args = types.SimpleNamespace(t=5, rand_t=False, t_delta=0, use_bm=False, sample_step=1, score_type="guided_diffusion")
 defender = RevImprovedDiffusion.from_model(unet, args)
