@@ -229,16 +229,19 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
 //  * the weights are pre-packed in the MFMA A-operand layout ([group][32-row tile][k'/8][lane][4]) and go L2 ->
 //    registers as dwordx4, one chunk ahead: no LDS, no stores, no bank traffic for them (LDS holds only the 16 KB
 //    double-buffered im2col tile, so more workgroups fit a CU).
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag) {
-  constexpr int BN = 128, BK = 16;
+  // 2 x 2 waves, each (BM/2 rows x BN/2 columns): BM x BN = 128 x 128, 128 x 64 (layers with few tiles), 64 x 128
+  // (64 <= Cout/g < 128: ResNeXt's grouped 3x3)
+  constexpr int BK = 16, NX = BM / 64, NY = BN / 64, EPT = BK * BN / 256, KSTEP = 256 / BN;
   __shared__ float Bs[2][BK][BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int j = lane & 31, hh = lane >> 5;
   const int Mg = a.Cout / a.groups, Cg = a.Cin / a.groups, KK = a.kh * a.kw, Kg = Cg * KK;
   const int HoWo = a.Ho * a.Wo, N = a.B * HoWo;
-  const int g = blockIdx.z, m0 = blockIdx.y * 128, n0 = blockIdx.x * BN;
-  const int nl = tid & 127, kq = tid >> 7;             // element i of a thread: chunk row kq + 2 i, column nl
+  const int g = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int nl = tid & (BN - 1), kq = tid / BN;        // element i of a thread: chunk row kq + KSTEP i, column nl
   const int n = n0 + nl;
   const bool nvalid = n < N;
   const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
@@ -246,14 +249,14 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   const int HW = a.H * a.W;
   const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg + kq) * HW;
   const int MT = (Mg + 31) / 32, KQ = Kg / 8, CPT = Cg / BK;   // row tiles, k' quads per row tile, chunks per tap
-  const f32x4 *af[2];
+  const f32x4 *af[NX];
 #pragma unroll
-  for (int x_ = 0; x_ < 2; x_++) {
-    const int mt = min((m0 >> 5) + 2 * wm + x_, MT - 1);       // a tile past the end re-reads the last one (never stored)
+  for (int x_ = 0; x_ < NX; x_++) {
+    const int mt = min((m0 >> 5) + NX * wm + x_, MT - 1);      // a tile past the end re-reads the last one (never stored)
     af[x_] = reinterpret_cast<const f32x4 *>(afrag) + ((size_t)g * MT + mt) * KQ * 64 + lane;
   }
   const int nchunk = KK * CPT;
-  float br[8];
+  float br[EPT];
   auto load_b = [&](int c) {                                   // chunk c = (tap r, channels c0 .. c0+15)
     const int r = c / CPT, c0 = (c - r * CPT) * BK;
     const int ky = r / a.kw, kx = r - ky * a.kw;
@@ -261,43 +264,43 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
     const bool ok = nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const float v = p[(size_t)(2 * i) * HW];
+    for (int i = 0; i < EPT; i++) {
+      const float v = p[(size_t)(KSTEP * i) * HW];
       br[i] = ok ? v : 0.f;
     }
   };
-  auto load_a = [&](f32x4(&aa)[2][2], int c) {
+  auto load_a = [&](f32x4(&aa)[NX][2], int c) {
 #pragma unroll
-    for (int x_ = 0; x_ < 2; x_++)
+    for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
       for (int q = 0; q < 2; q++) aa[x_][q] = af[x_][(size_t)(2 * c + q) * 64];
   };
   auto store_b = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) Bs[buf][kq + 2 * i][nl] = br[i];
+    for (int i = 0; i < EPT; i++) Bs[buf][kq + KSTEP * i][nl] = br[i];
   };
-  f32x16 acc[2][2];
+  f32x16 acc[NX][NY];
 #pragma unroll
-  for (int x_ = 0; x_ < 2; x_++)
+  for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
-    for (int y_ = 0; y_ < 2; y_++)
+    for (int y_ = 0; y_ < NY; y_++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[x_][y_][r] = 0.f;
-  auto compute = [&](const f32x4(&aa)[2][2], int buf) {
+  auto compute = [&](const f32x4(&aa)[NX][2], int buf) {
 #pragma unroll
     for (int s = 0; s < BK / 2; s++) {
-      float bf[2];
+      float bf[NY];
 #pragma unroll
-      for (int t = 0; t < 2; t++) bf[t] = Bs[buf][2 * s + hh][64 * wn + 32 * t + j];
+      for (int t = 0; t < NY; t++) bf[t] = Bs[buf][2 * s + hh][32 * NY * wn + 32 * t + j];
 #pragma unroll
-      for (int x_ = 0; x_ < 2; x_++)
+      for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
-        for (int y_ = 0; y_ < 2; y_++)
+        for (int y_ = 0; y_ < NY; y_++)
           acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x_][s >> 2][s & 3], bf[y_], acc[x_][y_], 0, 0, 0);
     }
   };
 
-  f32x4 a0[2][2], a1[2][2];
+  f32x4 a0[NX][2], a1[NX][2];
   load_a(a0, 0);
   load_b(0);
   store_b(0);
@@ -310,21 +313,21 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
     compute(a0, c & 1);
     store_b((c + 1) & 1);
 #pragma unroll
-    for (int x_ = 0; x_ < 2; x_++)
+    for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
       for (int q = 0; q < 2; q++) a0[x_][q] = a1[x_][q];
     __syncthreads();
   }
 #pragma unroll
-  for (int y_ = 0; y_ < 2; y_++) {
-    const int nn = n0 + 64 * wn + 32 * y_ + j;
+  for (int y_ = 0; y_ < NY; y_++) {
+    const int nn = n0 + 32 * NY * wn + 32 * y_ + j;
     if (nn < N) {
       const int ob = nn / HoWo, op = nn % HoWo;
 #pragma unroll
-      for (int x_ = 0; x_ < 2; x_++)
+      for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          const int m = m0 + 64 * wm + 32 * x_ + crowoff(r, hh);
+          const int m = m0 + 32 * NX * wm + 32 * x_ + crowoff(r, hh);
           if (m < Mg) {
             const int co = g * Mg + m;
             const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
@@ -448,7 +451,7 @@ __global__ void pool2d_kernel(const float *__restrict__ x, float *__restrict__ y
 using namespace ap;
 
 static int g_conv_no_frag = 0;     // ap_debug_conv_path(1): timing A/B against the LDS-staged 128 x 128 kernel
-static long long g_conv_frag_min_tiles = 256;   // one 128 x 128 tile per CU is enough for this kernel (swept: 512 / 256 / 128 / 64)
+static long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
 extern "C" int ap_debug_conv_path(int no_frag) {
   if (no_frag >= 16) g_conv_frag_min_tiles = no_frag;   // >= 16: set the tile-count threshold of the streamed-weight kernel
   else g_conv_no_frag = no_frag;
@@ -456,7 +459,7 @@ extern "C" int ap_debug_conv_path(int no_frag) {
 }
 
 // layers the streamed-weight kernel serves carry a second image behind the first
-static bool conv_has_frag(int Cout, int Cin_g, int groups) { return Cin_g % 16 == 0 && Cout / groups >= 128; }
+static bool conv_has_frag(int Cout, int Cin_g, int groups) { return Cin_g % 16 == 0 && Cout / groups >= 64; }
 static size_t conv_frag_elems(int Cout, int Cin_g, int kh, int kw, int groups) {
   const int Mg = Cout / groups;
   return (size_t)groups * ((Mg + 31) / 32) * 32 * Cin_g * kh * kw;
@@ -504,9 +507,18 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   // the 128 x 128 tile needs enough workgroups to fill 256 CUs; otherwise 4x as many 64 x 64 tiles win
   const long long tiles128 = ((N + 127) / 128) * ((Mg + 127) / 128) * (long long)groups;
   const bool many = tiles128 >= 512;
-  if (tiles128 >= g_conv_frag_min_tiles && conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
-    dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
-    conv2d_f32_big2_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a, wT + (size_t)Cout * (Cin / groups) * kh * kw);
+  if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
+    const float *afrag = wT + (size_t)Cout * (Cin / groups) * kh * kw;
+    if (Mg < 128) {                                             // 64 <= Cout/g < 128
+      dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
+      conv2d_f32_big2_kernel<64, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+    } else if (tiles128 >= g_conv_frag_min_tiles) {
+      dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+      conv2d_f32_big2_kernel<128, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+    } else {                                                    // few tiles (low-resolution layers): 128 x 64
+      dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+      conv2d_f32_big2_kernel<128, 64><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+    }
   } else if (Mg >= 128 && kh <= 3 && kw <= 3 && many) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
     conv2d_f32_big_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);

@@ -220,7 +220,7 @@ int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L
  *
  * ap_conv2d_pack: w [Cout][Cin/g][kh][kw] (times scale[Cout] if non-NULL, the folded BatchNorm gamma/sqrt(var+eps))
  *   -> wT [groups][ (Cin/g) kh kw ][Cout/g], the A-operand image of the implicit GEMM, followed (layers with
- *   Cin/g % 16 == 0 and Cout/g >= 128) by the same weights as MFMA A fragments in tap-major K order, which the
+ *   Cin/g % 16 == 0 and Cout/g >= 64) by the same weights as MFMA A fragments in tap-major K order, which the
  *   streamed-weight kernel reads straight from L2; allocate ap_conv2d_packed_elems(...) floats.
  * ap_conv2d_fwd: out = [relu]( conv2d(x, w, stride, pad, groups) + bias + res ), nn.Conv2d semantics (cross-correlation,
  *   zero padding); bias / res may be NULL; res has the shape of out.  conv-as-GEMM on v_mfma_f32_32x32x2_f32.

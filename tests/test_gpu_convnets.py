@@ -64,7 +64,9 @@ def test_conv2d_primitive_edge_shapes(dev):
     for (B, Cin, H, Cout, k, s, p, g) in [(3, 8, 9, 12, 3, 1, 1, 1), (2, 16, 16, 40, 3, 2, 1, 4), (5, 33, 7, 70, 1, 1, 0, 1),
                                           (1, 64, 4, 64, 3, 1, 1, 8), (4, 1, 32, 64, 3, 1, 1, 1),
                                           (33, 32, 32, 200, 3, 1, 1, 1), (70, 64, 31, 272, 3, 2, 1, 2),
-                                          (40, 48, 30, 160, 1, 1, 0, 1), (36, 24, 32, 136, 3, 1, 1, 1)]:
+                                          (40, 48, 30, 160, 1, 1, 0, 1), (36, 24, 32, 136, 3, 1, 1, 1),
+                                          (7, 32, 5, 200, 3, 1, 1, 1),           # few tiles: the 128 x 64 variant
+                                          (9, 128, 16, 176, 3, 1, 1, 2)]:        # Cout/g = 88: the 64 x 128 variant
         x = torch.from_numpy(synth.uniform(f"cx{Cin}{H}", (B, Cin, H, H), 1))
         w = torch.from_numpy(synth.uniform(f"cw{Cin}{Cout}", (Cout, Cin // g, k, k), 1))
         b = torch.from_numpy(synth.uniform(f"cb{Cout}", (Cout,), 1))
