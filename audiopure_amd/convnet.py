@@ -331,6 +331,13 @@ class NativeConvNet(nn.Module):
         self.plan = lower(module, self.input_chw)
         self._dev_weights = None
         self._dev = None
+        self._conv_flags = 0
+
+    def set_precision(self, mode: str):
+        """"f32": fp32 MFMA (default).  "f32s": eligible conv layers on the bf16 MFMA with exactly 3-way-split fp32
+        operands (AP_CONV_SPLIT) -- fp32-class results, faster."""
+        self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100}[mode]
+        return self
 
     def _get_name(self):                       # the scripts print / branch on the classifier's class name
         return self.module._get_name()
@@ -386,7 +393,7 @@ class NativeConvNet(nn.Module):
                 res = N.ptr(buf(p["res"])) if p["res"] is not None else None
                 N.check(lib.ap_conv2d_fwd(N.ptr(buf(v)), N.ptr(self._packed[i]), N.ptr(W[p["bk"]]) if p["bk"] else None, res,
                                           N.ptr(ob), B, v.C, v.H, v.W, o.C, p["kh"], p["kw"], p["stride"], p["pad"],
-                                          p["groups"], int(p["relu"]), v.cstride, v.coff, st_), "ap_conv2d_fwd")
+                                          p["groups"], int(p["relu"]) | self._conv_flags, v.cstride, v.coff, st_), "ap_conv2d_fwd")
             elif s.kind == "affine":
                 v = s.ins[0]
                 assert o.full

@@ -342,6 +342,180 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   }
 }
 
+// ---- the same kernel on the bf16 matrix pipe at fp32 accuracy (flags bit 8, AP_CONV_SPLIT) -----------------------
+// Operands split exactly into three bf16 parts, the six partial products >= 2^-16 of each product on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate (the arithmetic of ap_resblock_f32s.hip): 24 MFMAs of 32 cycles per
+// 16-row chunk and wave instead of 32 of 64.  Weights come pre-split as A fragments ([group][row tile][k'/16][split]
+// [lane][8 bf16]); a thread stages 8 consecutive k' of one column (8 gathers HW apart -> 3 ds_write_b128 into the
+// [column][k'] bf16 images, 48-B rows: conflict-free b128 fragment reads).
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void csplit3(float x, __bf16 (&p)[3]) {
+  p[0] = (__bf16)x;
+  const float r1 = x - (float)p[0];
+  p[1] = (__bf16)r1;
+  p[2] = (__bf16)(r1 - (float)p[1]);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const __bf16 *__restrict__ afrag) {
+  constexpr int BK = 16, NX = BM / 64, NY = BN / 64, RS = 48;   // RS: bytes per column row of a B image
+  constexpr int IMG = BN * RS;
+  static_assert(BN == 128, "staging map: 256 threads = 128 columns x 2 k' octets");
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][IMG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j = lane & 31, hh = lane >> 5;
+  const int Mg = a.Cout / a.groups, Cg = a.Cin / a.groups, KK = a.kh * a.kw, Kg = Cg * KK;
+  const int HoWo = a.Ho * a.Wo, N = a.B * HoWo;
+  const int g = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int nl = tid & (BN - 1), ko = tid / BN;        // this thread stages k' = 8 ko .. 8 ko + 7 of column nl
+  const int n = n0 + nl;
+  const bool nvalid = n < N;
+  const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const int HW = a.H * a.W;
+  const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg + 8 * ko) * HW;
+  const int MT = (Mg + 31) / 32, KS = Kg / 16, CPT = Cg / BK;
+  const cu32x4 *af[NX];
+#pragma unroll
+  for (int x_ = 0; x_ < NX; x_++) {
+    const int mt = min((m0 >> 5) + NX * wm + x_, MT - 1);
+    af[x_] = reinterpret_cast<const cu32x4 *>(afrag) + ((size_t)g * MT + mt) * KS * 3 * 64 + lane;
+  }
+  const int nchunk = KK * CPT;
+  float br[8];
+  auto load_b = [&](int c) {
+    const int r = c / CPT, c0 = (c - r * CPT) * BK;
+    const int ky = r / a.kw, kx = r - ky * a.kw;
+    const int iy = iy0 + ky, ix = ix0 + kx;
+    const bool ok = nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float v = p[(size_t)i * HW];
+      br[i] = ok ? v : 0.f;
+    }
+  };
+  auto load_a = [&](cbf16x8(&aa)[NX][3], int c) {
+#pragma unroll
+    for (int x_ = 0; x_ < NX; x_++)
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++) aa[x_][sp] = __builtin_bit_cast(cbf16x8, af[x_][(size_t)(3 * c + sp) * 64]);
+  };
+  auto store_b = [&](int buf) {
+    cu32x4 pk[3];
+#pragma unroll
+    for (int pr = 0; pr < 4; pr++) {
+      float v0 = br[2 * pr], v1 = br[2 * pr + 1];
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++) {
+        const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v0, v1}, cbf16x2));
+        pk[sp][pr] = w;
+        if (sp < 2) {
+          v0 -= __builtin_bit_cast(float, w << 16);
+          v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int sp = 0; sp < 3; sp++) *reinterpret_cast<cu32x4 *>(&Bs[buf][sp][nl * RS + ko * 16]) = pk[sp];
+  };
+  f32x16 acc[NX][NY];
+#pragma unroll
+  for (int x_ = 0; x_ < NX; x_++)
+#pragma unroll
+    for (int y_ = 0; y_ < NY; y_++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[x_][y_][r] = 0.f;
+  auto compute = [&](const cbf16x8(&aa)[NX][3], int buf) {
+#pragma unroll
+    for (int y_ = 0; y_ < NY; y_++) {
+      cbf16x8 bv[3];
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++)
+        bv[sp] = *reinterpret_cast<const cbf16x8 *>(&Bs[buf][sp][(32 * NY * wn + 32 * y_ + j) * RS + hh * 16]);
+#pragma unroll
+      for (int x_ = 0; x_ < NX; x_++) {
+#define AP_CT(i, jx) acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[x_][i], bv[jx], acc[x_][y_], 0, 0, 0);
+        AP_CT(0, 0) AP_CT(0, 1) AP_CT(1, 0) AP_CT(0, 2) AP_CT(2, 0) AP_CT(1, 1)
+#undef AP_CT
+      }
+    }
+  };
+  cbf16x8 a0[NX][3], a1[NX][3];
+  load_a(a0, 0);
+  load_b(0);
+  store_b(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < nchunk; c++) {
+    const int cn = c + 1 < nchunk ? c + 1 : c;
+    load_b(cn);
+    load_a(a1, cn);
+    compute(a0, c & 1);
+    store_b((c + 1) & 1);
+#pragma unroll
+    for (int x_ = 0; x_ < NX; x_++)
+#pragma unroll
+      for (int sp = 0; sp < 3; sp++) a0[x_][sp] = a1[x_][sp];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int y_ = 0; y_ < NY; y_++) {
+    const int nn = n0 + 32 * NY * wn + 32 * y_ + j;
+    if (nn < N) {
+      const int ob = nn / HoWo, op = nn % HoWo;
+#pragma unroll
+      for (int x_ = 0; x_ < NX; x_++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = m0 + 32 * NX * wm + 32 * x_ + crowoff(r, hh);
+          if (m < Mg) {
+            const int co = g * Mg + m;
+            const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
+            float v = acc[x_][y_][r];
+            if (a.bias) v += a.bias[co];
+            if (a.res) v += a.res[off];
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.out[off] = v;
+          }
+        }
+    }
+  }
+}
+
+// w -> 3-way split A fragments of v_mfma_f32_32x32x16_bf16, tap-major K: [group][row tile][k'/16][split][lane][8]
+__global__ void conv_pack_split_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                       __bf16 *__restrict__ out, int Cout, int Cg, int KK, int groups) {
+  const int Mg = Cout / groups, MT = (Mg + 31) / 32, Kg = Cg * KK, KS = Kg / 16;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per (.., lane, jj), all 3 splits
+  const size_t total = (size_t)groups * MT * KS * 64 * 8;
+  if (idx >= total) return;
+  const int jj = idx & 7, lane = (idx >> 3) & 63;
+  size_t rest = idx >> 9;
+  const int q = rest % KS; rest /= KS;
+  const int mt = rest % MT, g = rest / MT;
+  const int i = lane & 31, h = lane >> 5;
+  const int kp = 16 * q + 8 * h + jj;
+  const int r = kp / Cg, ci = kp - r * Cg;
+  const int m = 32 * mt + i;
+  float v = 0.f;
+  if (m < Mg) {
+    const int co = g * Mg + m;
+    v = w[((size_t)co * Cg + ci) * KK + r];
+    if (scale) v *= scale[co];
+  }
+  __bf16 p[3];
+  csplit3(v, p);
+  const size_t frag = (((size_t)g * MT + mt) * KS + q) * 3;
+#pragma unroll
+  for (int sp = 0; sp < 3; sp++) out[((frag + sp) * 64 + lane) * 8 + jj] = p[sp];
+}
+
 // w [Cout][Cin/g][kh][kw] (* scale) -> A-operand fragments of v_mfma_f32_32x32x2_f32 in tap-major K order:
 // [group][row tile MT][k'/8][lane 64][4], element e of quad q = k' pair 4q + e, lane = (row i, half h): k' = 2 pair + h
 __global__ void conv_pack_frag_kernel(const float *__restrict__ w, const float *__restrict__ scale,
@@ -465,10 +639,16 @@ static size_t conv_frag_elems(int Cout, int Cin_g, int kh, int kw, int groups) {
   return (size_t)groups * ((Mg + 31) / 32) * 32 * Cin_g * kh * kw;
 }
 
+// third image (3 x bf16 per weight = 1.5 floats), rounded up to whole float4s
+static size_t conv_split_floats(int Cout, int Cin_g, int kh, int kw, int groups) {
+  return (conv_frag_elems(Cout, Cin_g, kh, kw, groups) * 3 / 2 + 3) & ~(size_t)3;
+}
+
 extern "C" size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups) {
   if (Cout < 1 || Cin_g < 1 || kh < 1 || kw < 1 || groups < 1 || Cout % groups) return 0;
   size_t n = (size_t)Cout * Cin_g * kh * kw;
-  if (conv_has_frag(Cout, Cin_g, groups)) n += conv_frag_elems(Cout, Cin_g, kh, kw, groups);
+  if (conv_has_frag(Cout, Cin_g, groups))
+    n = ((n + 3) & ~(size_t)3) + conv_frag_elems(Cout, Cin_g, kh, kw, groups) + conv_split_floats(Cout, Cin_g, kh, kw, groups);
   return n;
 }
 
@@ -479,9 +659,11 @@ extern "C" int ap_conv2d_pack(const float *w, const float *scale, float *wT, int
   size_t n = (size_t)Cout * Kg;
   conv_pack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, scale, wT, Cout, Kg, groups);
   if (conv_has_frag(Cout, Cin_g, groups)) {
-    const size_t nf = conv_frag_elems(Cout, Cin_g, kh, kw, groups);
-    conv_pack_frag_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, scale, wT + n, Cout, Cin_g,
+    const size_t nf = conv_frag_elems(Cout, Cin_g, kh, kw, groups), n4 = (n + 3) & ~(size_t)3;   // 16-B aligned images
+    conv_pack_frag_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, scale, wT + n4, Cout, Cin_g,
                                                                                        kh * kw, groups);
+    conv_pack_split_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        w, scale, reinterpret_cast<__bf16 *>(wT + n4 + nf), Cout, Cin_g, kh * kw, groups);
   }
   AP_HIP(hipGetLastError());
   return 0;
@@ -498,6 +680,8 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   ConvArgs a;
   a.x = x; a.wT = wT; a.bias = bias; a.res = res; a.out = out;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+  const bool split = (relu >> 8) & 1;                            // flags: bit 0 ReLU, bit 8 AP_CONV_SPLIT
+  relu &= 1;
   a.groups = groups; a.relu = relu; a.x_cstride = x_cstride; a.x_coff = x_coff;
   a.Ho = (H + 2 * pad - kh) / stride + 1;
   a.Wo = (W + 2 * pad - kw) / stride + 1;
@@ -508,8 +692,18 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   const long long tiles128 = ((N + 127) / 128) * ((Mg + 127) / 128) * (long long)groups;
   const bool many = tiles128 >= 512;
   if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
-    const float *afrag = wT + (size_t)Cout * (Cin / groups) * kh * kw;
-    if (Mg < 128) {                                             // 64 <= Cout/g < 128
+    const size_t n1 = (size_t)Cout * (Cin / groups) * kh * kw;
+    const float *afrag = wT + ((n1 + 3) & ~(size_t)3);
+    if (split) {                                                // fp32 results on the bf16 pipe (3-way split operands)
+      const __bf16 *sfrag = reinterpret_cast<const __bf16 *>(afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups));
+      if (Mg < 128) {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
+        conv2d_split_kernel<64, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, sfrag);
+      } else {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+        conv2d_split_kernel<128, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, sfrag);
+      }
+    } else if (Mg < 128) {                                             // 64 <= Cout/g < 128
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
       conv2d_f32_big2_kernel<64, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
     } else if (tiles128 >= g_conv_frag_min_tiles) {

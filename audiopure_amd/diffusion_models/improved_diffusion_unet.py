@@ -121,12 +121,18 @@ class UNetModel(nn.Module):
         torch.cuda.synchronize(dev)
         self._packed, self._key = packed, key
 
+    def set_precision(self, mode: str):
+        """"f32": fp32 MFMA convolutions (default); "f32s": the bf16 MFMA with exactly 3-way-split fp32 operands
+        (AP_CONV_SPLIT): fp32-class results, faster."""
+        self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100}[mode]
+        return self
+
     def _conv(self, m, x, B, Cin, H, W, res=None):
         wT, bias, cout, kh, kw, stride, pad = self._packed[m]
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         out = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
         N.check(N.lib().ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, H, W, cout, kh, kw, stride,
-                                      pad, 1, 0, Cin, 0, N.stream()), "ap_conv2d_fwd")
+                                      pad, 1, getattr(self, "_conv_flags", 0), Cin, 0, N.stream()), "ap_conv2d_fwd")
         return out
 
     def _gn(self, gn, x, ss=None, act=2):

@@ -31,6 +31,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define AP_CONV_SPLIT 0x100
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -224,6 +226,8 @@ int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L
  *   streamed-weight kernel reads straight from L2; allocate ap_conv2d_packed_elems(...) floats.
  * ap_conv2d_fwd: out = [relu]( conv2d(x, w, stride, pad, groups) + bias + res ), nn.Conv2d semantics (cross-correlation,
  *   zero padding); bias / res may be NULL; res has the shape of out.  conv-as-GEMM on v_mfma_f32_32x32x2_f32.
+ *   `relu` is a flag word: bit 0 = fused ReLU, bit 8 (AP_CONV_SPLIT) = run eligible layers (Cin/g % 16 == 0,
+ *   Cout/g >= 64) on the bf16 MFMA with exactly 3-way-split fp32 operands (AP_PREC_F32_SPLIT's arithmetic).
  *   nn.Linear is the kh = kw = H = W = 1 case. */
 size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups);   /* floats ap_conv2d_pack writes */
 int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw, int groups,

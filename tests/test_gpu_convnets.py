@@ -54,8 +54,10 @@ def test_family_structures_match_module(dev):
     assert rel_err(NativeConvNet(m).eval()(x.to(dev)).cpu().numpy(), ref) < TOL
 
 
-def test_conv2d_primitive_edge_shapes(dev):
-    """ap_conv2d_fwd alone: grouped, strided, 1x1, Cout not a multiple of the tile, N not a multiple of the tile."""
+@pytest.mark.parametrize("flags", [0, 0x100])
+def test_conv2d_primitive_edge_shapes(dev, flags):
+    """ap_conv2d_fwd alone: grouped, strided, 1x1, Cout not a multiple of the tile, N not a multiple of the tile; with
+    flags = AP_CONV_SPLIT the eligible layers run on the bf16 MFMA with 3-way-split operands -- same tolerance."""
     import torch.nn.functional as F
     from audiopure_amd import _native as N
     lib = N.lib()
@@ -75,8 +77,8 @@ def test_conv2d_primitive_edge_shapes(dev):
         wT = torch.empty(lib.ap_conv2d_packed_elems(Cout, Cin // g, k, k, g), device=dev)
         N.check(lib.ap_conv2d_pack(N.ptr(wd), None, N.ptr(wT), Cout, Cin // g, k, k, g, N.stream()))
         out = torch.empty(ref.shape, device=dev)
-        N.check(lib.ap_conv2d_fwd(N.ptr(xd), N.ptr(wT), N.ptr(bd), None, N.ptr(out), B, Cin, H, H, Cout, k, k, s, p, g, 1,
-                                  Cin, 0, N.stream()))
+        N.check(lib.ap_conv2d_fwd(N.ptr(xd), N.ptr(wT), N.ptr(bd), None, N.ptr(out), B, Cin, H, H, Cout, k, k, s, p, g,
+                                  1 | flags, Cin, 0, N.stream()))
         assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6, (B, Cin, H, Cout, k, s, p, g)
 
 

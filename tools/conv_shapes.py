@@ -11,8 +11,10 @@ dev = torch.device("cuda:0")
 B = 256
 unet = synth_init(create_model(**model_and_diffusion_defaults()), 0).to(dev)
 args = types.SimpleNamespace(t=1, rand_t=False, t_delta=0, use_bm=False, sample_step=1, score_type="guided_diffusion")
+mode = sys.argv[1] if len(sys.argv) > 1 else 'f32'
+unet.set_precision(mode)
 defender = RevImprovedDiffusion.from_model(unet, args)
-clf = NativeConvNet(synth_init(CifarResNeXt(10), 0)).eval()
+clf = NativeConvNet(synth_init(CifarResNeXt(10), 0)).eval().set_precision(mode)
 system = AcousticSystem(classifier=clf, transform=MelSpecDB(32), defender=defender, defense_type="spec")
 x = (torch.rand(B, 1, 16000, device=dev) - 0.5)
 y = system(x, True); torch.cuda.synchronize()
