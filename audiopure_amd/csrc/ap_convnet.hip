@@ -915,6 +915,84 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
   }
 }
 
+// The same attention on the fp32 MFMA for the UNet's shapes (64 channels per head, T = 64 / 256 positions).
+// Everything is computed transposed so that nothing ever moves between lanes:
+//   S^T[key][query] = sum_c K[c][key] Q[c][query]   A = K from LDS (lane = key), B = Q in registers (lane = query)
+//   -> a lane owns ONE query and, in its accumulator registers, its scores against 16 keys per 32-key tile: the
+//      softmax maximum / sum run over the lane's own registers plus one xor-32 shuffle;
+//   O^T[c][query] = sum_key V[c][key] P[key][query]  B = P straight from those registers (the k-pair of an MFMA step is
+//      the pair of keys the two lane halves hold in the same register), A = V from a transposed LDS image (lane = channel).
+// One workgroup per (sample, head), one wave per 32-query block.
+template <int NT>                                               // NT = T / 32 key tiles (2 or 8)
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ out,
+                                                             float scale2) {
+  constexpr int CH = 64, T = 32 * NT, VS = CH + 1;
+  extern __shared__ float sm[];
+  float *ks = sm;                                               // [CH][T]
+  float *vt = sm + CH * T;                                      // [T][CH + 1]
+  const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const float *base = qkv + (size_t)bh * 3 * CH * T;
+  for (int i = tid; i < CH * T; i += 256) {
+    ks[i] = base[(size_t)CH * T + i];
+    const int c = i / T, t = i - c * T;
+    vt[t * VS + c] = base[(size_t)2 * CH * T + i];
+  }
+  __syncthreads();
+  for (int qb = wave; qb < NT; qb += 4) {
+    float q[CH / 2];
+#pragma unroll
+    for (int s2 = 0; s2 < CH / 2; s2++) q[s2] = base[(size_t)(2 * s2 + hh) * T + 32 * qb + j] * scale2;
+    f32x16 sc[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) sc[kt][r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < CH / 2; s2++)
+        sc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks[(2 * s2 + hh) * T + 32 * kt + j], q[s2], sc[kt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                        // keep the LDS operand reads of later tiles from piling up
+    }
+    // exact softmax over the keys of this lane's query (weights kept unnormalised; 1 / sum applied to the output)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        sc[kt][r] = expf(sc[kt][r] - mx);
+        l += sc[kt][r];
+      }
+    l += __shfl_xor(l, 32);
+    f32x16 o[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[ct][r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; kt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = 32 * kt + crowoff(r, hh);               // the key this lane half holds in register r
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++)
+          o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vt[key * VS + 32 * ct + j], sc[kt][r], o[ct], 0, 0, 0);
+        if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+    const float inv = 1.0f / l;
+    float *op = out + (size_t)bh * CH * T + 32 * qb + j;
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) op[(size_t)(32 * ct + crowoff(r, hh)) * T] = o[ct][r] * inv;
+  }
+}
+
 }  // namespace ap
 
 extern "C" int ap_groupnorm_nchw(const float *x, const float *gamma, const float *beta, const float *scale_shift, float *y,
@@ -956,6 +1034,18 @@ extern "C" int ap_attention_qkv(const float *qkv, float *out, int B, int C, int 
   const float scale2 = 1.0f / sqrtf((float)ch);          // (1/sqrt(sqrt(ch)))^2, unet.py:247-249
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(B * heads);
+  if (ch == 64 && (T == 64 || T == 256) && !g_conv_no_frag) {   // the UNet's shapes: fp32 MFMA
+    const size_t sm2 = (size_t)(64 * T + T * 65) * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      AP_HIP(hipFuncSetAttribute((const void *)attention_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr2 = true;
+    }
+    if (T == 64) attention_mfma_kernel<2><<<grid, 256, sm2, st>>>(qkv, out, scale2);
+    else attention_mfma_kernel<8><<<grid, 256, sm2, st>>>(qkv, out, scale2);
+    AP_HIP(hipGetLastError());
+    return 0;
+  }
 #define AP_ATT(CHV)                                                                                                  \
   do {                                                                                                               \
     static bool attr = false;                                                                                        \

@@ -41,7 +41,7 @@ def test_primitives_match_torch(dev):
     xd, gd, bd, sd_ = x.to(dev), g.to(dev), b.to(dev), ss.to(dev)      # keep the device copies alive across the launch
     N.check(lib.ap_groupnorm_nchw(N.ptr(xd), N.ptr(gd), N.ptr(bd), N.ptr(sd_), N.ptr(y), 3, 64, 64, 32, 1e-5, 2, N.stream()))
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 3e-6
-    for ch, T, heads in ((16, 256, 2), (64, 64, 4), (32, 100, 1)):
+    for ch, T, heads in ((16, 256, 2), (64, 64, 4), (32, 100, 1), (64, 256, 3)):     # the ch = 64 cases run on the MFMA
         qkv = torch.from_numpy(synth.uniform(f"qkv{ch}", (2, heads * 3 * ch, T), 1, -1.5, 1.5))
         q, k, v = torch.split(qkv.reshape(2 * heads, 3 * ch, T), ch, dim=1)
         w = torch.softmax(torch.einsum("bct,bcs->bts", q * ch ** -0.25, k * ch ** -0.25), dim=-1)
