@@ -632,13 +632,16 @@ int launch_affine_noise(const float *x, float *out, float ca, float cs, const fl
 // final_conv + clip update:  eps = W_f2 relu(W_f1 (skip * sqrt(1/N)) + b_f1) + b_f2;  out = ca x + cb eps + cs z
 // (WaveNet.py:135,160-162,170; diffwave_ddpm.py:159-160,99-102)
 // ---------------------------------------------------------------------------------------------
-template <int S>
-__global__ __launch_bounds__(S / 64 * 64, 1) void final_f32_kernel(
+// FT = columns per workgroup: 64 at S = 256 so that two workgroups share a CU (64 KB of LDS each) and one's staging
+// runs under the other's MFMAs.
+template <int S, int FT>
+__global__ __launch_bounds__(S / 64 * 64, FT == 64 ? 2 : 1) void final_f32_kernel(
     const float *__restrict__ skip, const float *__restrict__ x, float *__restrict__ eps_out, float *__restrict__ out,
     const float *__restrict__ wf1p, const float *__restrict__ bf1, const float *__restrict__ wf2,
     const float *__restrict__ bf2, float scale, float ca, float cb, float cs, const float *__restrict__ z,
     uint64_t seed, uint32_t draw, uint64_t utt_offset, int L, int ntiles) {
   constexpr int NW = S / 64, NT = NW * 64, NG = S / 8;
+  constexpr int TT = FT, NCT = FT / 32;                        // shadows ap::TT
   __shared__ float lds[S * TT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -649,18 +652,18 @@ __global__ __launch_bounds__(S / 64 * 64, 1) void final_f32_kernel(
 
   // stage skip * sqrt(1/N)  ->  lds[S][TT]
   for (int e = tid; e < S * TT; e += NT) {
-    const int row = e >> 7, col = e & 127;
+    const int row = e / TT, col = e % TT;
     const int t = t0 + col;
     lds[e] = (t < L) ? sk[(size_t)row * L + t] * scale : 0.f;
   }
-  f32x16 acc[2][4];
+  f32x16 acc[2][NCT];
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       float bv = bf1[64 * wave + 32 * rt + rowoff(r, hh)];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) acc[rt][ct][r] = bv;
+      for (int ct = 0; ct < NCT; ct++) acc[rt][ct][r] = bv;
     }
   __syncthreads();
 
@@ -677,34 +680,36 @@ __global__ __launch_bounds__(S / 64 * 64, 1) void final_f32_kernel(
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const int s = Gi * 4 + e;
-      float bv[4];
+      float bv[NCT];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) bv[ct] = lds[(2 * s + hh) * TT + 32 * ct + j];
+      for (int ct = 0; ct < NCT; ct++) bv[ct] = lds[(2 * s + hh) * TT + 32 * ct + j];
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++)
+        for (int ct = 0; ct < NCT; ct++)
           acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[rt][e], bv[ct], acc[rt][ct], 0, 0, 0);
     }
     a_cur[0] = a_nxt[0];
     a_cur[1] = a_nxt[1];
   }
   // relu, dot with W_f2 over this wave's 64 rows
-  float part[4] = {0.f, 0.f, 0.f, 0.f};
+  float part[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ct++) part[ct] = 0.f;
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const float w = wf2[64 * wave + 32 * rt + rowoff(r, hh)];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) part[ct] = __builtin_fmaf(fmaxf(acc[rt][ct][r], 0.f), w, part[ct]);
+      for (int ct = 0; ct < NCT; ct++) part[ct] = __builtin_fmaf(fmaxf(acc[rt][ct][r], 0.f), w, part[ct]);
     }
 #pragma unroll
-  for (int ct = 0; ct < 4; ct++) part[ct] += __shfl_xor(part[ct], 32);
+  for (int ct = 0; ct < NCT; ct++) part[ct] += __shfl_xor(part[ct], 32);
   __syncthreads();   // all MFMA reads of lds retired
   if (hh == 0) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) lds[wave * TT + 32 * ct + j] = part[ct];
+    for (int ct = 0; ct < NCT; ct++) lds[wave * TT + 32 * ct + j] = part[ct];
   }
   __syncthreads();
   for (int col = tid; col < TT; col += NT) {
@@ -731,16 +736,17 @@ int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *e
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st) {
   const int S = ctx->S;
-  const int ntiles = (L + TT - 1) / TT;
+  const int ft = (S == 256) ? 64 : TT;
+  const int ntiles = (L + ft - 1) / ft;
   const float scale = (float)sqrt(1.0 / (double)ctx->NL);   // math.sqrt(1.0/N) (WaveNet.py:135)
   unsigned grid = (unsigned)B * ntiles;
-#define AP_FINAL(SS)                                                                                             \
-  final_f32_kernel<SS><<<grid, SS, 0, st>>>(skip, x, eps_out, out, ctx->wf1p, ctx->bf1, ctx->wf2, ctx->bf2, scale, \
-                                            ca, cb, cs, z, seed, draw, utt_offset, L, ntiles)
+#define AP_FINAL(SS, FTV)                                                                                         \
+  final_f32_kernel<SS, FTV><<<grid, SS, 0, st>>>(skip, x, eps_out, out, ctx->wf1p, ctx->bf1, ctx->wf2, ctx->bf2,   \
+                                                 scale, ca, cb, cs, z, seed, draw, utt_offset, L, ntiles)
   switch (S) {
-    case 64: AP_FINAL(64); break;
-    case 128: AP_FINAL(128); break;
-    case 256: AP_FINAL(256); break;
+    case 64: AP_FINAL(64, 128); break;
+    case 128: AP_FINAL(128, 128); break;
+    case 256: AP_FINAL(256, 64); break;
     default:
       set_error("final: unsupported skip_channels %d", S);
       return -22;
