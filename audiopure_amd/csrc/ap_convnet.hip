@@ -16,6 +16,7 @@ struct ConvArgs {
   const float *x, *wT, *bias, *res;
   float *out;
   int B, Cin, H, W, Cout, Ho, Wo, kh, kw, stride, pad, groups, relu;
+  int pad_h, dil_h, dil_w;   // pad applies to W; pad_h / dil_h to H (equal to pad / dil_w except in 1-D mode: 0 / 1)
   int x_cstride;     // channels of the tensor x lives in (>= Cin when x is a channel slice of a wider tensor)
   int x_coff;        // first channel of the slice
 };
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
   const int n = n0 + nl;
   const bool nvalid = n < N;
   const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
-  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad_h, ix0 = (pp % a.Wo) * a.stride - a.pad;
   const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg) * a.H * a.W;
   // A loader: thread -> row m = tid & 63, k rows (tid >> 6) + 4 i ; wT is [groups][Kg][Mg]
   const float *wg = a.wT + (size_t)g * Kg * Mg;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
       if (k < Kg) {
         if (mvalid) av = wg[(size_t)k * Mg + m0 + nl];
         const int ci = k / KK, r = k - ci * KK, ky = r / a.kw, kx = r - ky * a.kw;
-        const int iy = iy0 + ky, ix = ix0 + kx;
+        const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
         if (nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) bv = xb[((size_t)ci * a.H + iy) * a.W + ix];
       }
       ar[i] = av;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
   const int n = n0 + nl;
   const bool nvalid = n < N;
   const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
-  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad_h, ix0 = (pp % a.Wo) * a.stride - a.pad;
   const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg) * a.H * a.W;
   const float *wg = a.wT + (size_t)g * Kg * Mg;
   const bool mvalid = (m0 + nl) < Mg;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
         if (mvalid) av = wg[(size_t)k * Mg + m0 + nl];
         const int r = rr[i];
         const int ky = (r >= a.kw) + (r >= 2 * a.kw), kx = r - ky * a.kw;
-        const int iy = iy0 + ky, ix = ix0 + kx;
+        const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
         if (nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) bv = xb[(size_t)ci[i] * HW + iy * a.W + ix];
       }
       ar[i] = av;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   const int n = n0 + nl;
   const bool nvalid = n < N;
   const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
-  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad_h, ix0 = (pp % a.Wo) * a.stride - a.pad;
   const int HW = a.H * a.W;
   const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg + kq) * HW;
   const int MT = (Mg + 31) / 32, KQ = Kg / 8, CPT = Cg / BK;   // row tiles, k' quads per row tile, chunks per tap
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   auto load_b = [&](int c) {                                   // chunk c = (tap r, channels c0 .. c0+15)
     const int r = c / CPT, c0 = (c - r * CPT) * BK;
     const int ky = r / a.kw, kx = r - ky * a.kw;
-    const int iy = iy0 + ky, ix = ix0 + kx;
+    const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
     const bool ok = nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
 #pragma unroll
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
   const int n = n0 + nl;
   const bool nvalid = n < N;
   const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
-  const int iy0 = (pp / a.Wo) * a.stride - a.pad, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad_h, ix0 = (pp % a.Wo) * a.stride - a.pad;
   const int HW = a.H * a.W;
   const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg + 8 * ko) * HW;
   const int MT = (Mg + 31) / 32, KS = Kg / 16, CPT = Cg / BK;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
   auto load_b = [&](int c) {
     const int r = c / CPT, c0 = (c - r * CPT) * BK;
     const int ky = r / a.kw, kx = r - ky * a.kw;
-    const int iy = iy0 + ky, ix = ix0 + kx;
+    const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
     const bool ok = nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
 #pragma unroll
@@ -680,11 +681,17 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   ConvArgs a;
   a.x = x; a.wT = wT; a.bias = bias; a.res = res; a.out = out;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
-  const bool split = (relu >> 8) & 1;                            // flags: bit 0 ReLU, bit 8 AP_CONV_SPLIT
+  // flags: bit 0 ReLU, bit 8 AP_CONV_SPLIT, bit 9 AP_CONV_1D (padding and dilation apply to W only: Conv1d over
+  // [B][C][1][L]), bits 16-31 dilation (0 = 1)
+  const bool split = (relu >> 8) & 1, one_d = (relu >> 9) & 1;
+  const int dil = (relu >> 16) ? (relu >> 16) : 1;
   relu &= 1;
   a.groups = groups; a.relu = relu; a.x_cstride = x_cstride; a.x_coff = x_coff;
-  a.Ho = (H + 2 * pad - kh) / stride + 1;
-  a.Wo = (W + 2 * pad - kw) / stride + 1;
+  a.dil_w = dil;
+  a.dil_h = one_d ? 1 : dil;
+  a.pad_h = one_d ? 0 : pad;
+  a.Ho = (H + 2 * a.pad_h - a.dil_h * (kh - 1) - 1) / stride + 1;
+  a.Wo = (W + 2 * pad - a.dil_w * (kw - 1) - 1) / stride + 1;
   if (a.Ho < 1 || a.Wo < 1) { set_error("ap_conv2d_fwd: empty output"); return -22; }
   const long long N = (long long)B * a.Ho * a.Wo;
   const int Mg = Cout / groups;

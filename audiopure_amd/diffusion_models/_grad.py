@@ -1,0 +1,192 @@
+"""Input gradient of the purification chain.
+
+The reference's white-box adaptive attack back-propagates a loss through the defender
+(``robustness_eval/white_box_attack.py:392,437-439``; the scripts build ``RevDiffWave`` whose
+``torchsde.sdeint_adjoint`` re-integrates backwards, ``diffusion_models/diffwave_sde.py:200-204``).
+Every sampler here is a chain of links ``x <- ca x + cb eps(x, t) + cs z`` (``ap_step``), so the gradient is
+
+    dL/dx_t = ca dL/dx_{t-1} + cb J_eps(x_t, t)^T dL/dx_{t-1}
+
+with the states x_t check-pointed in the forward pass and one eps-evaluation recomputed per link in the backward
+pass (the adjoint's memory/compute trade: only the 37 layer inputs of ONE evaluation are ever live).
+
+``J_eps^T v`` runs on the HIP library: the residual blocks' forward is the fused kernel (``ap_resblock_fwd``), the
+three GEMM-shaped backward terms of a block -- the recomputed dilated conv, ``W2^T [dh'; dskip]`` and the transposed
+dilated conv -- are ``ap_conv2d_fwd`` calls in ``AP_CONV_1D`` mode (MFMA conv-as-GEMM, weights streamed as
+fragments), with ``ap_gate_bwd`` / ``ap_relu_outer_bwd`` / ``ap_init_conv_bwd`` between them.  Gradients with respect
+to the network's parameters are not formed (the attack differentiates with respect to the audio only; parameters
+are frozen at evaluation, ``adaptive_attack_eval.py:98-101``).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .. import _native as N
+
+_RS = 0.707106781186547524
+_F1D = 0x200                      # AP_CONV_1D
+
+
+class EpsGrad:
+    """Backward weights of one WaveNet_Speech_Commands plus eps forward-with-save / backward."""
+
+    def __init__(self, net):
+        self.net = net
+        self._key = None
+
+    # ---- weights ---------------------------------------------------------------------------------------
+    def _prepare(self):
+        net = self.net
+        eng = net.engine()
+        key = (id(eng), eng.loaded_key)
+        if self._key == key:
+            return eng
+        lib, dev = eng.lib, next(net.parameters()).device
+        C_, S_, NL = eng.cfg.res_channels, eng.cfg.skip_channels, eng.cfg.num_res_layers
+        cyc = eng.cfg.dilation_cycle
+
+        def folded(which, layer, n):
+            t = torch.empty(n, device=dev, dtype=torch.float32)
+            N.check(lib.ap_ctx_get_folded(eng.ctx, which, layer, N.ptr(t), n, N.stream()), "ap_ctx_get_folded")
+            return t
+
+        def pack(w4):                                           # [Cout][Cin][kh][kw] -> packed images
+            w4 = w4.contiguous()
+            co, ci, kh, kw = w4.shape
+            out = torch.empty(lib.ap_conv2d_packed_elems(co, ci, kh, kw, 1), device=dev, dtype=torch.float32)
+            N.check(lib.ap_conv2d_pack(N.ptr(w4), None, N.ptr(out), co, ci, kh, kw, 1, N.stream()), "ap_conv2d_pack")
+            return out
+
+        self.layers = []
+        blocks = net.residual_layer.residual_blocks
+        for n in range(NL):
+            w1 = folded(0, n, 2 * C_ * C_ * 3).reshape(2 * C_, C_, 1, 3)
+            w2 = torch.cat([folded(1, n, C_ * C_).reshape(C_, C_), folded(2, n, S_ * C_).reshape(S_, C_)], 0)   # [(C+S)][C]
+            self.layers.append(dict(
+                d=2 ** (n % cyc),
+                a=pack(w1),                                                           # u -> pre-gate a   (C -> 2C, k=3, dil d)
+                g=pack(w2.t().reshape(C_, C_ + S_, 1, 1)),                            # [RS dh'; dskip] -> dg  (C+S -> C, 1x1)
+                u=pack(w1.flip(3).permute(1, 0, 2, 3)),                               # da -> du   (2C -> C, k=3 flipped, dil d)
+                b1=blocks[n].dilated_conv_layer.conv.bias.detach().float().contiguous()))
+        s = float(torch.tensor(math.sqrt(1.0 / NL), dtype=torch.float32))             # WaveNet.py:135
+        wf1 = folded(3, 0, S_ * S_).reshape(S_, S_) * s
+        self.wf1 = pack(wf1.reshape(S_, S_, 1, 1))                                    # skip_sum -> r (scale folded in)
+        self.wf1_t = pack(wf1.t().reshape(S_, S_, 1, 1))                              # dr -> dskip
+        self.bf1 = net.final_conv[0].conv.bias.detach().float().contiguous()
+        self.wf2 = net.final_conv[2].conv.weight.detach().float().reshape(-1).contiguous()
+        self.w0 = folded(4, 0, C_)
+        self.ones = torch.ones(C_, device=dev)
+        self.C, self.S, self.NL = C_, S_, NL
+        torch.cuda.synchronize(dev)
+        self._key = key
+        return eng
+
+    def _conv(self, lib, x, packed, bias, res, out, B, Cin, L, Cout, kw, pad, dil, flags=0):
+        if self.net._precision == N.AP_PREC_F32_SPLIT:           # follow the network's arithmetic mode (AP_CONV_SPLIT)
+            flags |= 0x100
+        fl = flags | _F1D | ((dil << 16) if dil > 1 else 0)
+        N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(packed), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, 1, L, Cout, 1, kw, 1,
+                                  pad, 1, fl, Cin, 0, N.stream()), "ap_conv2d_fwd")
+
+    # ---- one eps evaluation, keeping what its backward needs ---------------------------------------------------
+    def forward_save(self, x: torch.Tensor, step: float):
+        eng = self._prepare()
+        lib, dev = eng.lib, x.device
+        B, _, L = x.shape
+        C_, S_, NL = self.C, self.S, self.NL
+        part = torch.empty(NL * C_ + eng.cfg.embed_dim_out, device=dev)
+        N.check(lib.ap_embed(eng.ctx, float(step), N.ptr(part), N.stream()), "ap_embed")
+        hs = torch.empty((NL + 1, B, C_, L), device=dev)
+        skip = torch.empty((B, S_, L), device=dev)
+        N.check(lib.ap_init_conv(eng.ctx, N.ptr(x), N.ptr(hs[0]), B, L, N.stream()), "ap_init_conv")
+        for n in range(NL):
+            N.check(lib.ap_resblock_fwd(eng.ctx, n, N.ptr(hs[n]), N.ptr(part[n * C_:(n + 1) * C_]), N.ptr(hs[n + 1]), N.ptr(skip),
+                                        1 if n else 0, B, L, N.stream()), "ap_resblock_fwd")
+        eps = torch.empty((B, 1, L), device=dev)
+        N.check(lib.ap_final_affine(eng.ctx, N.ptr(skip), None, N.ptr(eps), None, 0.0, 0.0, 0.0, None, 0, 0, 0, B, L,
+                                    N.stream()), "ap_final_affine")
+        return eps, (hs, skip, part)
+
+    def backward(self, saved, d_eps: torch.Tensor) -> torch.Tensor:
+        """J_eps(x, t)^T d_eps for the evaluation ``saved`` came from."""
+        eng = self._prepare()
+        lib = eng.lib
+        hs, skip, part = saved
+        NL, C_, S_ = self.NL, self.C, self.S
+        B, L, dev = hs.shape[1], hs.shape[3], hs.device
+        d_eps = d_eps.detach().float().contiguous()
+        st = N.stream()
+        # final_conv: r = W_f1 (skip s) + b_f1; eps = w_f2 . relu(r) + b_f2
+        r = torch.empty((B, S_, L), device=dev)
+        self._conv(lib, skip, self.wf1, self.bf1, None, r, B, S_, L, S_, 1, 0, 1)
+        dr = torch.empty_like(r)
+        N.check(lib.ap_relu_outer_bwd(N.ptr(r), N.ptr(self.wf2), N.ptr(d_eps), N.ptr(dr), B, S_, L, st), "ap_relu_outer_bwd")
+        z = torch.empty((B, C_ + S_, L), device=dev)             # [RS dh' ; dskip], dskip is the same for every block
+        dskip = r                                                 # reuse
+        self._conv(lib, dr, self.wf1_t, None, None, dskip, B, S_, L, S_, 1, 0, 1)
+        N.check(lib.ap_copy_channels(N.ptr(dskip), N.ptr(z), B, S_, L, S_, 0, C_ + S_, C_, st), "ap_copy_channels")
+        dh = torch.zeros((B, C_, L), device=dev)                  # the last block's h' output is not used (WaveNet.py:133)
+        t1 = torch.empty_like(dh)
+        dg = torch.empty_like(dh)
+        u = torch.empty_like(dh)
+        a = torch.empty((B, 2 * C_, L), device=dev)
+        da = torch.empty_like(a)
+        nel = dh.numel()
+        for n in range(NL - 1, -1, -1):
+            lay = self.layers[n]
+            d = lay["d"]
+            N.check(lib.ap_axpbyc(N.ptr(dh), None, N.ptr(t1), _RS, 0.0, 0.0, nel, st), "ap_axpbyc")
+            N.check(lib.ap_copy_channels(N.ptr(t1), N.ptr(z), B, C_, L, C_, 0, C_ + S_, 0, st), "ap_copy_channels")
+            self._conv(lib, z, lay["g"], None, None, dg, B, C_ + S_, L, C_, 1, 0, 1)
+            pt = part[n * C_:(n + 1) * C_]
+            N.check(lib.ap_affine_nchw(N.ptr(hs[n]), N.ptr(self.ones), N.ptr(pt), N.ptr(u), B, C_, L, C_, 0, 0, st),
+                    "ap_affine_nchw")
+            self._conv(lib, u, lay["a"], lay["b1"], None, a, B, C_, L, 2 * C_, 3, d, d)
+            N.check(lib.ap_gate_bwd(N.ptr(a), N.ptr(dg), N.ptr(da), B, C_, L, st), "ap_gate_bwd")
+            self._conv(lib, da, lay["u"], None, t1, dh, B, 2 * C_, L, C_, 3, d, d)
+        dx = torch.empty((B, 1, L), device=dev)
+        N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")
+        return dx
+
+
+class _ChainFn(torch.autograd.Function):
+    """x_out = chain(x_in): q-sample then the links (step, ca, cb, cs); noise tensors given explicitly."""
+
+    @staticmethod
+    def forward(ctx, x, grad, steps, qa, qs, zs):
+        """zs[k] = draw k of the chain ([B,1,L]); draw 0 is the q-sample's (the numbering of ap_purify_chain)."""
+        xs = []
+        cur = x.detach().float().contiguous()
+        if qs != 0.0:
+            cur = qa * cur + qs * zs[0]
+        elif qa != 1.0:
+            cur = qa * cur
+        with torch.no_grad():
+            for (t, ca, cb, cs, draw) in steps:
+                xs.append(cur)
+                eps, _ = grad.forward_save(cur, t)
+                nxt = ca * cur + cb * eps
+                if cs != 0.0 and draw:
+                    nxt = nxt + cs * zs[draw]
+                cur = nxt
+        ctx.grad, ctx.steps, ctx.qa, ctx.xs = grad, steps, qa, xs
+        return cur
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.detach().float().contiguous()
+        with torch.no_grad():
+            for (t, ca, cb, cs, draw), xt in zip(reversed(ctx.steps), reversed(ctx.xs)):
+                _, saved = ctx.grad.forward_save(xt, t)          # recompute this link's evaluation (adjoint-style)
+                g = ca * g + cb * ctx.grad.backward(saved, g)
+                del saved
+        return ctx.qa * g, None, None, None, None, None
+
+
+def differentiable_chain(net, x, steps, qa, qs, zs):
+    """The sampling chain as an autograd node (gradient with respect to ``x`` only)."""
+    if not hasattr(net, "_eps_grad"):
+        net._eps_grad = EpsGrad(net)
+    return _ChainFn.apply(x, net._eps_grad, list(steps), float(qa), float(qs), zs)

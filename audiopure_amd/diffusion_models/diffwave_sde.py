@@ -16,6 +16,7 @@ import math
 import numpy as np
 import torch
 
+from .. import _native as N
 from .diffwave_ddpm import DiffWave, create_diffwave_model
 
 
@@ -117,6 +118,8 @@ class RevDiffWave(torch.nn.Module):
         assert audio.ndim == 3, audio.ndim
         if self.rev_vpsde.score_type != 'guided_diffusion':
             raise NotImplementedError(f'Unknown score type in RevVPSDE: {self.rev_vpsde.score_type}!')
+        if torch.is_grad_enabled() and audio.requires_grad:
+            return self._differentiable_sample(audio)
         x0 = self.model._prep(audio)
         xs = []
         with torch.no_grad():
@@ -129,6 +132,35 @@ class RevDiffWave(torch.nn.Module):
                 steps = self.rev_vpsde.euler_steps(total_noise_levels)
                 x0 = self.model._chain(x0, steps, math.sqrt(a), math.sqrt(1.0 - a), n_draws=total_noise_levels + 1)
                 xs.append(x0)
+        return torch.cat(xs, dim=0)
+
+    def _differentiable_sample(self, audio):
+        """The same Euler chain as an autograd node: the white-box attack's ``loss.backward()`` reaches the audio
+        (white_box_attack.py:392,437-439; the reference gets there through sdeint_adjoint, diffwave_sde.py:200-204).
+        States are check-pointed per step and each step's eps-evaluation is recomputed in the backward pass."""
+        from ._grad import differentiable_chain
+        if audio.dim() != 3 or audio.shape[1] != 1:
+            raise ValueError(f"expected audio of shape [B,1,L], got {tuple(audio.shape)}")
+        dw = self.model
+        dev = next(dw.model.parameters()).device
+        x = audio.to(dev).float()
+        xs = []
+        for it in range(self.args.sample_step):
+            total_noise_levels = self.args.t
+            if self.args.rand_t:
+                total_noise_levels = self.args.t + np.random.randint(-self.args.t_delta, self.args.t_delta)
+            a = float(self.rev_vpsde.alphas_cumprod[total_noise_levels - 1].double())
+            steps = self.rev_vpsde.euler_steps(total_noise_levels)
+            dw._tables()
+            z_all, seed, off = dw._draws(total_noise_levels + 1, x.detach())
+            if z_all is None:                                    # in-kernel Philox stream: materialise the same draws
+                B, _, L = x.shape
+                z_all = torch.empty((total_noise_levels + 1, B, L), device=dev)
+                for k in range(total_noise_levels + 1):
+                    N.check(N.lib().ap_philox_normal(N.ptr(z_all[k]), seed, k, off, B, L, N.stream()), "ap_philox_normal")
+            zs = z_all.reshape(z_all.shape[0], x.shape[0], 1, x.shape[2])
+            x = differentiable_chain(dw.model, x, steps, math.sqrt(a), math.sqrt(1.0 - a), zs)
+            xs.append(x)
         return torch.cat(xs, dim=0)
 
     def forward(self, x):

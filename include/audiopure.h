@@ -32,6 +32,8 @@
 #include <stdint.h>
 
 #define AP_CONV_SPLIT 0x100
+#define AP_CONV_1D 0x200
+#define AP_CONV_DILATION(d) ((d) << 16)
 
 #ifdef __cplusplus
 extern "C" {
@@ -227,7 +229,8 @@ int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L
  * ap_conv2d_fwd: out = [relu]( conv2d(x, w, stride, pad, groups) + bias + res ), nn.Conv2d semantics (cross-correlation,
  *   zero padding); bias / res may be NULL; res has the shape of out.  conv-as-GEMM on v_mfma_f32_32x32x2_f32.
  *   `relu` is a flag word: bit 0 = fused ReLU, bit 8 (AP_CONV_SPLIT) = run eligible layers (Cin/g % 16 == 0,
- *   Cout/g >= 64) on the bf16 MFMA with exactly 3-way-split fp32 operands (AP_PREC_F32_SPLIT's arithmetic).
+ *   Cout/g >= 64) on the bf16 MFMA with exactly 3-way-split fp32 operands (AP_PREC_F32_SPLIT's arithmetic); bit 9
+ *   (AP_CONV_1D) = padding and dilation apply to W only (nn.Conv1d over [B][C][1][L]); bits 16-31 = dilation (0 = 1).
  *   nn.Linear is the kh = kw = H = W = 1 case. */
 size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups);   /* floats ap_conv2d_pack writes */
 int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw, int groups,
@@ -271,6 +274,16 @@ int ap_psample_update(const float *x, const float *eps, const float *z, float *o
 /* Fill out[B][L] with the library's Philox N(0,1) stream (same values the fused paths use). */
 int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                      void *stream);
+
+/* ---- input gradient of the eps-network (reference: the white-box attack back-propagates through
+ * the defender, robustness_eval/white_box_attack.py:392,437-439; diffwave_sde.py:200-204 sdeint_adjoint).  The GEMM-shaped
+ * terms run on ap_conv2d_fwd (AP_CONV_1D + dilation); these are the element-wise pieces between them. ---- */
+/* WaveNet.py:90 backward: a = [a_t; a_s] [B][2C][L], dg [B][C][L] -> da [B][2C][L] */
+int ap_gate_bwd(const float *a, const float *dg, float *da, int B, int C, int L, void *stream);
+/* WaveNet.py:160-162 backward through the ReLU: dr[b][c][t] = r > 0 ? w2[c] deps[b][t] : 0 */
+int ap_relu_outer_bwd(const float *r, const float *w2, const float *deps, float *dr, int B, int S, int L, void *stream);
+/* WaveNet.py:147,168 backward: dx[b][t] = sum_c [h0 > 0] w0[c] dh0[b][c][t] */
+int ap_init_conv_bwd(const float *h0, const float *w0, const float *dh0, float *dx, int B, int C, int L, void *stream);
 
 #ifdef __cplusplus
 }

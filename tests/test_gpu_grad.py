@@ -1,0 +1,100 @@
+"""gradient of a loss through the purifier with respect to the audio, HIP path vs torch autograd
+through the CPU oracle (the oracle's eps-network is plain differentiable torch ops)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from audiopure_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _net(cfg, dev, seed=0):
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+    sd = synth.wavenet_state_dict(cfg, seed)
+    net = WaveNet_Speech_Commands(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net.to(dev), sd
+
+
+@pytest.mark.parametrize("C_,NL,L,step", [(64, 12, 1000, 3.0), (128, 5, 777, 0.0), (256, 3, 640, 17.0)])
+def test_eps_vjp_matches_oracle_autograd(dev, C_, NL, L, step):
+    """J_eps(x, t)^T v for a random cotangent v: every backward piece (final conv, 3 GEMMs per block incl. dilations
+    1..2048 >= L, gate derivative, init conv) against autograd through the oracle."""
+    from oracle import diffwave_oracle as O
+    from audiopure_amd.diffusion_models._grad import EpsGrad
+    cfg = synth.mini_wavenet_config(C_, NL, 12)
+    net, sd = _net(cfg, dev, seed=5)
+    w = O.fold_state_dict(sd)
+    B = 2
+    x = torch.from_numpy(synth.waveforms(B, L, seed=11))
+    v = torch.from_numpy(synth.uniform(f"v{L}", (B, 1, L), 1, -1.0, 1.0))
+    xr = x.clone().requires_grad_(True)
+    eps_ref = O.eps_net(w, cfg, xr, torch.full((B, 1), step))
+    (g_ref,) = torch.autograd.grad(eps_ref, xr, v)
+    eg = EpsGrad(net)
+    eps, saved = eg.forward_save(x.to(dev), step)
+    assert rel_err(eps.cpu().numpy(), eps_ref.detach().numpy()) < 2e-5
+    g = eg.backward(saved, v.to(dev))
+    assert rel_err(g.cpu().numpy(), g_ref.numpy()) < 1e-4
+
+
+def test_white_box_gradient_through_rev_diffwave_matches_oracle(dev):
+    """loss(classifier-free surrogate: sum of w * purified) differentiated w.r.t. the audio through RevDiffWave's Euler
+    chain (t* = 3), as white_box_attack.py:392,437-439 does; reference = autograd through the oracle's SDE chain."""
+    from oracle import diffwave_oracle as O
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    cfg = synth.mini_wavenet_config(64, 12, 12)
+    net, sd = _net(cfg, dev, seed=2)
+    w = O.fold_state_dict(sd)
+    dh = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+    t_star, B, L = 3, 2, 1200
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=t_star)
+    args = types.SimpleNamespace(t=t_star, rand_t=False, t_delta=0, use_bm=False, sample_step=1, score_type="guided_diffusion")
+    runner = RevDiffWave.from_model(dw, args)
+    zs = [torch.from_numpy(synth.noise(d, B, L, seed=9)) for d in range(t_star + 1)]
+    wgt = torch.from_numpy(synth.uniform("lossw", (B, 1, L), 1, -1.0, 1.0))
+    x = torch.from_numpy(synth.waveforms(B, L, seed=9))
+    # HIP path
+    dw.set_noise_source([z.clone() for z in zs])
+    xd = x.to(dev).requires_grad_(True)
+    out = runner(xd)
+    loss = (out * wgt.to(dev)).sum()
+    loss.backward()
+    # oracle: the same Euler links with autograd
+    xr = x.clone().requires_grad_(True)
+    steps = runner.rev_vpsde.euler_steps(t_star)
+    a = float(runner.rev_vpsde.alphas_cumprod[t_star - 1].double())
+    cur = np.sqrt(a) * xr + np.sqrt(1.0 - a) * zs[0].reshape(B, 1, L)
+    for (t, ca, cb, cs, draw) in steps:
+        eps = O.eps_net(w, cfg, cur, torch.full((B, 1), float(t)))
+        cur = ca * cur + cb * eps + (cs * zs[draw].reshape(B, 1, L) if cs != 0.0 else 0.0)
+    loss_ref = (cur * wgt).sum()
+    loss_ref.backward()
+    assert rel_err(out.detach().cpu().numpy(), cur.detach().numpy()) < 1e-4
+    # the gradient passes through two ReLU masks (init conv, final conv): forward differences of 1e-6 flip a mask at
+    # isolated samples, so the max-norm tolerance is looser than the typical agreement
+    ga, gr = xd.grad.cpu().numpy(), xr.grad.numpy()
+    assert rel_err(ga, gr) < 1e-3
+    assert float(np.median(np.abs(ga - gr))) < 2e-6 * float(np.abs(gr).max())
+    # forward-only calls still refuse to pretend: DiffWave.forward is no_grad in the reference (diffwave_ddpm.py:41-43)
+    with pytest.raises(NotImplementedError):
+        dw(x.to(dev).requires_grad_(True))
