@@ -10,6 +10,27 @@ import torch.nn as nn
 from ... import _native as N
 
 
+class _M5InputGrad(torch.autograd.Function):
+    """log-probabilities with the gradient w.r.t. the waveform formed by ap_m5_bwd (white_box_attack.py:392,437-439)."""
+
+    @staticmethod
+    def forward(ctx, x, mod):
+        with torch.no_grad():
+            out = mod.forward(x.detach())
+        ctx.mod = mod
+        ctx.save_for_backward(x.detach().float().contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.detach().float().contiguous()
+        dx = torch.empty_like(x)
+        N.check(N.lib().ap_m5_bwd(ctx.mod._handle(), N.ptr(x), N.ptr(g), N.ptr(dx), x.shape[0], x.shape[2], N.stream()),
+                "ap_m5_bwd")
+        return dx, None
+
+
 class M5(nn.Module):
     def __init__(self, n_input=1, first_kernel_size=80, n_output=35, stride=16, n_channel=32):
         super().__init__()
@@ -67,7 +88,7 @@ class M5(nn.Module):
         if self.training:
             raise NotImplementedError("audiopure_amd M5: inference only (BatchNorm folded); call .eval()")
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("audiopure_amd M5: forward-only HIP path; autograd through it is not implemented")
+            return _M5InputGrad.apply(x, self)                   # white-box attack: dL/dx (parameters frozen)
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError(f"expected [B,1,L], got {tuple(x.shape)}")
         h = self._handle()

@@ -539,6 +539,11 @@ extern "C" int ap_m5_destroy(ap_m5 *m) {
   return 0;
 }
 
+extern "C" int ap_m5_bwd(ap_m5 *m, const float *x, const float *dlogprobs, float *dx, int B, int L, void *stream) {
+  if (!m || !x || !dlogprobs || !dx || B < 1) { set_error("ap_m5_bwd: bad argument"); return -22; }
+  return launch_m5_bwd(m, x, dlogprobs, dx, B, L, (hipStream_t)stream);
+}
+
 extern "C" int ap_m5_fwd(ap_m5 *m, const float *x, float *logprobs, int B, int L, void *stream) {
   if (!m || !x || !logprobs || B < 1) { set_error("ap_m5_fwd: bad argument"); return -22; }
   return launch_m5(m, x, logprobs, B, L, (hipStream_t)stream);

@@ -97,5 +97,6 @@ int launch_pack_split(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);
 int launch_m5(ap_m5 *m, const float *x, float *logprobs, int B, int L, hipStream_t st);
+int launch_m5_bwd(ap_m5 *m, const float *x, const float *dlogp, float *dx, int B, int L, hipStream_t st);
 int launch_m5_fold(ap_m5 *m, const float *blob, float bn_eps, hipStream_t st);
 }  // namespace ap
