@@ -64,6 +64,7 @@ SIGNATURES = {
     "ap_m5_blob_elems": (_sz, [_i, _i, _i]),
     "ap_m5_fwd": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_melspec_db": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_argmax_hist": (_i, [_fp, _vp, _i, _i, _vp]),
     "ap_m5_bwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _vp]),
     "ap_gate_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_relu_outer_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _vp]),

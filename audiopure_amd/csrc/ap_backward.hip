@@ -52,9 +52,28 @@ __global__ void init_conv_bwd_kernel(const float *__restrict__ h0, const float *
   dx[(size_t)b * L + t] = s;
 }
 
+// votes of a batch of score rows into a running histogram (certified_robust.py:58-65: argmax per sample, then a
+// per-class count); first maximum wins like Tensor.max
+__global__ void argmax_hist_kernel(const float *__restrict__ scores, long long *__restrict__ counts, int B, int K) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float *r = scores + (size_t)b * K;
+  int am = 0;
+  for (int k = 1; k < K; k++)
+    if (r[k] > r[am]) am = k;
+  atomicAdd(reinterpret_cast<unsigned long long *>(counts + am), 1ull);
+}
+
 }  // namespace ap
 
 using namespace ap;
+
+extern "C" int ap_argmax_hist(const float *scores, long long *counts, int B, int K, void *stream) {
+  if (!scores || !counts || B < 1 || K < 1) { set_error("ap_argmax_hist: bad argument"); return -22; }
+  argmax_hist_kernel<<<(B + 255) / 256, 256, 0, (hipStream_t)stream>>>(scores, counts, B, K);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int ap_gate_bwd(const float *a, const float *dg, float *da, int B, int C, int L, void *stream) {
   if (!a || !dg || !da || B < 1 || C < 1 || L < 1) { set_error("ap_gate_bwd: bad argument"); return -22; }

@@ -282,6 +282,8 @@ int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offs
 int ap_gate_bwd(const float *a, const float *dg, float *da, int B, int C, int L, void *stream);
 /* WaveNet.py:160-162 backward through the ReLU: dr[b][c][t] = r > 0 ? w2[c] deps[b][t] : 0 */
 int ap_relu_outer_bwd(const float *r, const float *w2, const float *deps, float *dr, int B, int S, int L, void *stream);
+/* counts[argmax_k scores[b][k]] += 1 for b < B (int64 device histogram; certified_robust.py:58-65) */
+int ap_argmax_hist(const float *scores, long long *counts, int B, int K, void *stream);
 /* M5.forward (M5Net.py:20-38) backward with respect to the waveform: dlogprobs [B][n_output] -> dx [B][1][L] */
 int ap_m5_bwd(ap_m5 *m, const float *x, const float *dlogprobs, float *dx, int B, int L, void *stream);
 /* WaveNet.py:147,168 backward: dx[b][t] = sum_c [h0 > 0] w0[c] dh0[b][c][t] */
