@@ -756,6 +756,51 @@ int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *e
   return 0;
 }
 
+// ---- NES queries of the black-box attack (robustness_eval/_NES.py:14-55) with counter-based noise ----------------
+// copy s of audio a: lead (s == 0 when `lead`) is the unperturbed audio, then S/2 copies x + sigma z_p and S/2 copies
+// x - sigma z_p (antithetic pairs, :19-23); z_p = Philox(seed, draw, a * S/2 + p) is regenerated by the gradient
+// kernel, so the [A][S][L] noise tensor of the reference never exists.
+__global__ void nes_perturb_kernel(const float *__restrict__ x, float *__restrict__ out, float sigma, uint64_t seed,
+                                   uint32_t draw, int S, int lead, int L) {
+  const int a = blockIdx.z, s = blockIdx.y;                     // s over S + lead copies
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, t = 4 * q;
+  if (t >= L) return;
+  const int half = S / 2, sp = s - lead;
+  float zz[4] = {0.f, 0.f, 0.f, 0.f};
+  float sgn = 0.f;
+  if (sp >= 0) {
+    const int p = sp < half ? sp : sp - half;
+    sgn = sp < half ? sigma : -sigma;
+    philox_normal4(seed, draw, (uint64_t)a * half + p, (uint32_t)q, zz);
+  }
+  const float *xa = x + (size_t)a * L;
+  float *o = out + ((size_t)a * (S + lead) + s) * L;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (t + i < L) o[t + i] = __builtin_fmaf(sgn, zz[i], xa[t + i]);
+}
+
+// grad[a][t] (+)= (1/S) sum_p (loss[a][p] - loss[a][p + S/2]) z_p[t]    (:44-48: mean over copies of loss * noise)
+__global__ void nes_grad_kernel(const float *__restrict__ loss, float *__restrict__ grad, uint64_t seed, uint32_t draw,
+                                int S, int L, int accumulate) {
+  const int a = blockIdx.y;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, t = 4 * q;
+  if (t >= L) return;
+  const int half = S / 2;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < half; p++) {
+    float zz[4];
+    philox_normal4(seed, draw, (uint64_t)a * half + p, (uint32_t)q, zz);
+    const float w = loss[(size_t)a * S + p] - loss[(size_t)a * S + half + p];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc[i] = __builtin_fmaf(w, zz[i], acc[i]);
+  }
+  float *g = grad + (size_t)a * L;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (t + i < L) g[t + i] = (accumulate ? g[t + i] : 0.f) + acc[i] / (float)S;
+}
+
 __global__ void philox_fill_kernel(float *__restrict__ out, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                                    int L) {
   const int b = blockIdx.y;
@@ -787,6 +832,24 @@ extern "C" int ap_debug_trace(void *buf) {
 extern "C" int ap_debug_ablate(int mask) {
   ap::g_ablate = mask;
   ap::g_ablate_bf16 = mask;
+  return 0;
+}
+
+extern "C" int ap_nes_perturb(const float *x, float *out, float sigma, uint64_t seed, uint32_t draw, int A, int S,
+                              int lead, int L, void *stream) {
+  if (!x || !out || A < 1 || S < 2 || (S & 1) || L < 1 || lead < 0 || lead > 1) { ap::set_error("ap_nes_perturb: bad argument"); return -22; }
+  dim3 grid((unsigned)(((L + 3) / 4 + 255) / 256), (unsigned)(S + lead), (unsigned)A);
+  ap::nes_perturb_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(x, out, sigma, seed, draw, S, lead, L);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ap_nes_grad(const float *loss, float *grad, uint64_t seed, uint32_t draw, int A, int S, int L,
+                           int accumulate, void *stream) {
+  if (!loss || !grad || A < 1 || S < 2 || (S & 1) || L < 1) { ap::set_error("ap_nes_grad: bad argument"); return -22; }
+  dim3 grid((unsigned)(((L + 3) / 4 + 255) / 256), (unsigned)A);
+  ap::nes_grad_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(loss, grad, seed, draw, S, L, accumulate);
+  AP_HIP(hipGetLastError());
   return 0;
 }
 

@@ -282,6 +282,14 @@ int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offs
 int ap_gate_bwd(const float *a, const float *dg, float *da, int B, int C, int L, void *stream);
 /* WaveNet.py:160-162 backward through the ReLU: dr[b][c][t] = r > 0 ? w2[c] deps[b][t] : 0 */
 int ap_relu_outer_bwd(const float *r, const float *w2, const float *deps, float *dr, int B, int S, int L, void *stream);
+/* NES queries of the black-box attack (robustness_eval/_NES.py:14-55) with counter-based noise: ap_nes_perturb writes,
+ * per audio a, [lead unperturbed copy,] S/2 copies x + sigma z_p and S/2 copies x - sigma z_p (z_p = Philox(seed, draw,
+ * a S/2 + p)) into out [A][S + lead][L]; ap_nes_grad forms grad[a] (+)= (1/S) sum_p (loss[a][p] - loss[a][p + S/2]) z_p
+ * from the per-copy losses [A][S], regenerating z_p -- the reference's [A][S][L] noise tensor never exists. */
+int ap_nes_perturb(const float *x, float *out, float sigma, uint64_t seed, uint32_t draw, int A, int S, int lead, int L,
+                   void *stream);
+int ap_nes_grad(const float *loss, float *grad, uint64_t seed, uint32_t draw, int A, int S, int L, int accumulate,
+                void *stream);
 /* counts[argmax_k scores[b][k]] += 1 for b < B (int64 device histogram; certified_robust.py:58-65) */
 int ap_argmax_hist(const float *scores, long long *counts, int B, int K, void *stream);
 /* M5.forward (M5Net.py:20-38) backward with respect to the waveform: dlogprobs [B][n_output] -> dx [B][1][L] */

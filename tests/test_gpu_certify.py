@@ -65,3 +65,56 @@ def test_certify_and_randomised_smoothing_paths():
         assert y_pred.shape == y.shape and radius.shape == y.shape
         for i in range(2):
             assert (y_pred[i] == -1 and radius[i] == 0) or (0 <= y_pred[i] < 10 and radius[i] > 0 and math.isfinite(float(radius[i])))
+
+
+def test_nes_queries_and_gradient_estimate_match_the_reference_formula():
+    """robustness_eval/_NES.py:14-55 restated with the SAME noise materialised (Philox draws): antithetic copies, the
+    unperturbed lead copy of the first batch, mean(loss * noise) / sigma / num_batches."""
+    from audiopure_amd import _native as N
+    from audiopure_amd.robustness_eval._NES import NES
+    dev = torch.device("cuda:0")
+    A, L, S, spd, sigma = 3, 4000, 10, 30, 0.001
+    x = torch.from_numpy(synth.waveforms(A, L, seed=8)).to(dev)
+    wgt = torch.from_numpy(synth.uniform("nesw", (1, 1, L), 1, -1.0, 1.0)).to(dev)
+    seen = []
+
+    class Wrap:                                         # stands in for robustness_eval/_EOT.py:EOT (use_grad=False)
+        EOT_size, EOT_batch_size = 1, 1
+
+        def __call__(self, xb, yb):
+            seen.append(xb.clone())
+            s = (xb * wgt).sum(dim=(1, 2))
+            scores = torch.stack([s, -s, 0.5 * s], 1)
+            loss = s + 0.1 * s * s + 0.01 * yb.float()
+            dec = [[int(v)] for v in scores.argmax(1).cpu().reshape(-1)]
+            return scores, loss, None, [sum((dec[a * (xb.shape[0] // A) + k] for k in range(xb.shape[0] // A)), []) for a in range(A)]
+
+    nes = NES(spd, S, sigma, Wrap())
+    nes.seed = 5
+    y = [1, 2, 0]
+    mean_loss, grad, adver_loss, adver_score, predict = nes(x, y)
+    assert grad.shape == x.shape and adver_loss.shape == (A,) and adver_score.shape == (A, 3) and len(predict) == A
+    # reference arithmetic on the materialised noise
+    g_ref = torch.zeros_like(x)
+    ml_ref = torch.zeros(A, device=dev)
+    for i in range(spd // S):
+        z = torch.empty((A * (S // 2), L), device=dev)
+        N.check(N.lib().ap_philox_normal(N.ptr(z), 5, i, 0, A * (S // 2), L, N.stream()))
+        noise = z.reshape(A, S // 2, 1, L)
+        noise = torch.cat((noise, -noise), 1)
+        if i == 0:
+            noise = torch.cat((torch.zeros_like(x).unsqueeze(1), noise), 1)
+        ev = (noise * sigma + x.unsqueeze(1)).view(-1, 1, L)
+        assert torch.allclose(seen[i], ev, rtol=0, atol=1e-7)
+        yb = torch.tensor(y, device=dev).repeat_interleave(noise.shape[1])
+        _, loss, _, _ = Wrap()(ev, yb)
+        loss = loss.view(A, -1)
+        if i == 0:
+            assert torch.allclose(adver_loss, loss[:, 0])
+            loss, noise = loss[:, 1:], noise[:, 1:]
+        g_ref += torch.mean(loss.unsqueeze(2).unsqueeze(3) * noise, 1)
+        ml_ref += loss.mean(1)
+    g_ref = g_ref / sigma / (spd // S)
+    assert torch.allclose(mean_loss, ml_ref / (spd // S), atol=1e-6)
+    err = float((grad - g_ref).abs().max() / g_ref.abs().max())
+    assert err < 1e-3, err          # the estimate is a difference of nearly equal losses: fp32 cancellation on both sides
