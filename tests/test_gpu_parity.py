@@ -429,6 +429,35 @@ def test_split_full_chain_matches_reference_golden_at_the_fp32_tolerance(golden,
                                  reverse_timestep=5).one_shot_denoise(x0).cpu().numpy()) < TOL_EVAL
 
 
+def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
+    """Hazard / tiling sweep: the three residual-block kernels (fp32 MFMA, split-operand, bf16) against each other over
+    lengths that hit every code path (L % 4 != 0 -> dword paths, partial last tiles, single tile, d >= L, d in {1,2} vs
+    d % 4 == 0 staging), two launches back to back, batch sizes that are not powers of two.  fp32 vs split: 2e-6;
+    bf16 vs fp32: the bf16 operand rounding (3e-2 of max)."""
+    from audiopure_amd import _native as N
+    C_ = 256
+    cfg = synth.mini_wavenet_config(C_, 12, 12)
+    net, _ = _net(cfg, dev, seed=11)
+    rng = np.random.default_rng(0)
+    cases = [(3, 128, 0), (1, 129, 1), (5, 1024, 2), (2, 1028, 7), (3, 3999, 4), (2, 4000, 11), (7, 640, 9), (1, 16000, 5)]
+    cases += [(int(rng.integers(1, 6)), int(rng.integers(130, 5000)), int(rng.integers(0, 12))) for _ in range(6)]
+    for B, L, layer in cases:
+        h = torch.from_numpy(synth.uniform(f"sw/{L}/{layer}", (B, C_, L), 1, -1.5, 1.5)).to(dev)
+        sk0 = torch.from_numpy(synth.uniform(f"sws/{L}/{layer}", (B, C_, L), 1, -1.0, 1.0)).to(dev)
+        pt = torch.from_numpy(synth.uniform(f"swp/{layer}", (C_,), 1, -0.5, 0.5)).to(dev)
+        outs = {}
+        for mode in ("f32", "f32s", "bf16"):
+            net.set_precision(mode)
+            eng = net.engine()
+            sk, ho = sk0.clone(), torch.empty_like(h)
+            for _ in range(2):                                   # second launch accumulates onto the first's skip
+                N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho), N.ptr(sk), 1, B, L, N.stream()))
+            outs[mode] = (ho.cpu().numpy(), sk.cpu().numpy())
+        for k in (0, 1):
+            assert rel_err(outs["f32s"][k], outs["f32"][k]) < 2e-6, (B, L, layer, k)
+            assert rel_err(outs["bf16"][k], outs["f32"][k]) < 3e-2, (B, L, layer, k)
+
+
 def test_c_entry_points_match_python_chains(mini, dh, dev):
     """ap_purify_ddpm / ap_purify_sde / ap_one_shot_denoise (coefficients computed inside the library from the installed
     tables) give the same result as the chains the Python classes build with ap_purify_chain."""
