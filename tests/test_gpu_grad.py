@@ -176,3 +176,48 @@ def test_white_box_loss_gradient_end_to_end(dev):
     ga, gr = xd.grad.cpu().numpy(), xr.grad.numpy()
     assert rel_err(ga, gr) < 2e-3
     assert float(np.median(np.abs(ga - gr))) < 1e-5 * float(np.abs(gr).max())
+
+
+def test_pgd_step_and_eot_calls_of_the_reference_attack_work_unchanged(dev):
+    """The exact call pattern of white_box_attack.py:380-440 (delta leaf, x_pert = x + delta, model(x_pert),
+    criterion(...).backward(), delta.grad) and of _EOT.py:27-52 (repeat, retain_grad, backward(ones), .grad of the
+    repeated batch) against the native AcousticSystem."""
+    import torch.nn.functional as F
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    from audiopure_amd.audio_models.M5.M5Net import M5
+    from audiopure_amd.acoustic_system import AcousticSystem
+    cfg = synth.mini_wavenet_config(64, 12, 12)
+    net, _ = _net(cfg, dev, seed=2)
+    dw = DiffWave(model=net, diffusion_hyperparams=calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG), reverse_timestep=2)
+    runner = RevDiffWave.from_model(dw, types.SimpleNamespace(t=2, rand_t=False, t_delta=0, use_bm=False, sample_step=1,
+                                                              score_type="guided_diffusion"))
+    m5 = M5(n_input=1, n_output=10)
+    m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
+    model = AcousticSystem(classifier=m5.to(dev).eval(), transform=None, defender=runner, defense_type="wave")
+    B, L = 2, 16000
+    x = torch.from_numpy(synth.waveforms(B, L, seed=12)).to(dev)
+    y = torch.tensor([2, 5], device=dev)
+    dw.set_noise_source(("philox", 3, 0))
+    # PGD iteration
+    delta = torch.zeros_like(x, requires_grad=True)
+    y_pert = model(x + delta)
+    loss = F.cross_entropy(y_pert, y)
+    loss.backward()
+    g1 = delta.grad.clone()
+    assert g1.shape == x.shape and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    delta.data = delta.data + 0.001 * g1.sign()
+    # EOT with use_grad=True, EOT_batch_size = 3
+    x_pert = x + delta
+    rep = x_pert.repeat(3, 1, 1)
+    rep.retain_grad()
+    scores = model(rep)
+    loss_eot = F.cross_entropy(scores, y.repeat(3), reduction="none")
+    loss_eot.backward(torch.ones_like(loss_eot))
+    g_eot = rep.grad.view(3, -1, 1, L).mean(0)
+    assert g_eot.shape == x.shape and torch.isfinite(g_eot).all() and float(g_eot.abs().max()) > 0
+    # same Philox key and the same utterance indices for the first B rows -> the first replica reproduces a plain call
+    delta2 = delta.detach().clone().requires_grad_(True)
+    F.cross_entropy(model(x + delta2), y, reduction="sum").backward()
+    assert rel_err(rep.grad[:B].cpu().numpy(), delta2.grad.cpu().numpy()) < 1e-5
