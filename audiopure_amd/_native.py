@@ -64,6 +64,11 @@ SIGNATURES = {
     "ap_m5_blob_elems": (_sz, [_i, _i, _i]),
     "ap_m5_fwd": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_melspec_db": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_kws_blob_elems": (C.c_size_t, [_i, _i, _i]),
+    "ap_kws_create": (_i, [_i, _i, _i, _fp, _sz, _vp, C.POINTER(C.c_void_p)]),
+    "ap_kws_destroy": (_i, [_vp]),
+    "ap_kws_fwd": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
+    "ap_melspec_db_htk": (_i, [_fp, _fp, _i, _i, _i, _vp]),
     "ap_nes_perturb": (_i, [_fp, _fp, _f, _u64, _u32, _i, _i, _i, _i, _vp]),
     "ap_nes_grad": (_i, [_fp, _fp, _u64, _u32, _i, _i, _i, _i, _vp]),
     "ap_argmax_hist": (_i, [_fp, _vp, _i, _i, _vp]),

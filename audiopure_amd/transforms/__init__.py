@@ -1,2 +1,2 @@
 """Device-side classifier front-end transforms."""
-from .melspec import MelSpecDB, ToMelSpectrogramDB  # noqa: F401
+from .melspec import MelSpecDB, MelSpecDBHTK, ToMelSpectrogramDB  # noqa: F401

@@ -33,3 +33,25 @@ class MelSpecDB(torch.nn.Module):
 
 class ToMelSpectrogramDB(MelSpecDB):
     mode = 1
+
+
+class MelSpecDBHTK(torch.nn.Module):
+    """The KWS script's front-end (kws_adaptive_attack_eval.py:65-67): torchaudio ``MelSpectrogram(sample_rate=16000,
+    n_mels)`` with its defaults (n_fft = win = 400, hop = 200, reflect padding, HTK mel scale, no filter norm) followed
+    by ``AmplitudeToDB('power')``; clips of any length >= 201 samples."""
+
+    def __init__(self, n_mels: int = 40):
+        super().__init__()
+        self.n_mels = n_mels
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("audiopure_amd MelSpecDBHTK: forward-only HIP path")
+        lead = x.shape[:-1]
+        L = x.shape[-1]
+        xf = x.detach().float().reshape(-1, L).contiguous()
+        B = xf.shape[0]
+        frames = 1 + L // 200
+        out = torch.empty((B, self.n_mels, frames), device=xf.device, dtype=torch.float32)
+        N.check(N.lib().ap_melspec_db_htk(N.ptr(xf), N.ptr(out), self.n_mels, B, L, N.stream()), "ap_melspec_db_htk")
+        return out.reshape(*lead, self.n_mels, frames)

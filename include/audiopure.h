@@ -275,6 +275,20 @@ int ap_psample_update(const float *x, const float *eps, const float *z, float *o
 int ap_philox_normal(float *out, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                      void *stream);
 
+/* ---- keyword-spotting route: clips of any length ----
+ * ap_kws_*: KWSModel.forward (audio_models/RCNN_KWS/model.py:66-114): depthwise Conv1d(k=5, s=2) + grouped pointwise
+ * Conv1d(s=8), 2-layer bidirectional GRU, additive attention, linear, log-softmax.  `blob_dev`: the state dict
+ * concatenated in state-dict order.  mel [B][n_mels][T] -> log-probabilities [B][num_classes].
+ * ap_melspec_db_htk: the front-end that script builds (kws_adaptive_attack_eval.py:65-67):
+ * torchaudio MelSpectrogram(sample_rate=16000, n_mels) with default n_fft = 400, hop = 200, reflect padding, HTK scale,
+ * + AmplitudeToDB('power').  x [B][1][L] -> [B][1][n_mels][1 + L/200]. */
+typedef struct ap_kws ap_kws;
+size_t ap_kws_blob_elems(int n_mels, int hidden, int num_classes);
+int ap_kws_create(int n_mels, int hidden, int num_classes, const float *blob_dev, size_t n_elems, void *stream, ap_kws **out);
+int ap_kws_destroy(ap_kws *k);
+int ap_kws_fwd(ap_kws *k, const float *mel, float *logprobs, int B, int T, void *stream);
+int ap_melspec_db_htk(const float *x, float *out, int n_mels, int B, int L, void *stream);
+
 /* ---- input gradient of the eps-network (reference: the white-box attack back-propagates through
  * the defender, robustness_eval/white_box_attack.py:392,437-439; diffwave_sde.py:200-204 sdeint_adjoint).  The GEMM-shaped
  * terms run on ap_conv2d_fwd (AP_CONV_1D + dilation); these are the element-wise pieces between them. ---- */
