@@ -27,6 +27,6 @@ def run(mask, layer, reps=5):
     return ms, 16.777e9 * B / ms / 1e9
 if len(sys.argv) > 5: lib.ap_debug_stagger(int(sys.argv[5]))
 for layer in (5,):
-    for mask in (0, 1, 16, 32, 8, 9, 15):
+    for mask in (0, 1):
         ms, tf = run(mask, layer)
         print(f"layer {layer:2d} mask {mask:2d}: {ms:8.3f} ms  {tf:7.1f} TFLOP/s-equivalent", flush=True)
