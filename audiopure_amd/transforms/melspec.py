@@ -11,6 +11,30 @@ import torch
 from .. import _native as N
 
 
+class _MelGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod):
+        with torch.no_grad():
+            out = mod.forward(x.detach())
+        ctx.n_mels = mod.n_mels
+        ctx.save_for_backward(x.detach().float().contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        L = x.shape[-1]
+        xf = x.reshape(-1, L)
+        B = xf.shape[0]
+        frames = 1 + L // 512
+        gf = g.detach().float().reshape(B, ctx.n_mels, frames).contiguous()
+        dx = torch.empty_like(xf)
+        scratch = torch.empty((B, frames, 2048), device=x.device, dtype=torch.float32)
+        N.check(N.lib().ap_melspec_db_bwd(N.ptr(xf), N.ptr(gf), N.ptr(dx), N.ptr(scratch), ctx.n_mels, B, L, N.stream()),
+                "ap_melspec_db_bwd")
+        return dx.reshape(x.shape), None
+
+
 class MelSpecDB(torch.nn.Module):
     mode = 0
 
@@ -20,7 +44,9 @@ class MelSpecDB(torch.nn.Module):
 
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("audiopure_amd MelSpecDB: forward-only HIP path")
+            if self.mode != 0:
+                raise NotImplementedError("audiopure_amd ToMelSpectrogramDB: forward-only HIP path")
+            return _MelGrad.apply(x, self)                       # white-box attack: d/dx by ap_melspec_db_bwd
         lead = x.shape[:-1]
         L = x.shape[-1]
         xf = x.detach().float().reshape(-1, L).contiguous()

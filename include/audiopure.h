@@ -306,6 +306,8 @@ int ap_nes_grad(const float *loss, float *grad, uint64_t seed, uint32_t draw, in
                 void *stream);
 /* counts[argmax_k scores[b][k]] += 1 for b < B (int64 device histogram; certified_robust.py:58-65) */
 int ap_argmax_hist(const float *scores, long long *counts, int B, int K, void *stream);
+/* mode-0 ap_melspec_db backward with respect to the waveform: dout [B][n_mels][F] -> dx [B][1][L]; scratch: B F 2048 floats */
+int ap_melspec_db_bwd(const float *x, const float *dout, float *dx, float *scratch, int n_mels, int B, int L, void *stream);
 /* M5.forward (M5Net.py:20-38) backward with respect to the waveform: dlogprobs [B][n_output] -> dx [B][1][L] */
 int ap_m5_bwd(ap_m5 *m, const float *x, const float *dlogprobs, float *dx, int B, int L, void *stream);
 /* WaveNet.py:147,168 backward: dx[b][t] = sum_c [h0 > 0] w0[c] dh0[b][c][t] */
