@@ -72,6 +72,10 @@ SIGNATURES = {
     "ap_nes_perturb": (_i, [_fp, _fp, _f, _u64, _u32, _i, _i, _i, _i, _vp]),
     "ap_nes_grad": (_i, [_fp, _fp, _u64, _u32, _i, _i, _i, _i, _vp]),
     "ap_argmax_hist": (_i, [_fp, _vp, _i, _i, _vp]),
+    "ap_acc_channels": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ap_relu_mask": (_i, [_fp, _fp, _fp, _sz, _vp]),
+    "ap_zero_insert2d": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ap_pool2d_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ap_melspec_db_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_m5_bwd": (_i, [_vp, _fp, _fp, _fp, _i, _i, _vp]),
     "ap_gate_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _vp]),

@@ -320,6 +320,24 @@ def _fuse(plan: Plan):
 # ---------------------------------------------------------------------------------------------------------
 # 3. executor
 # ---------------------------------------------------------------------------------------------------------
+class _ConvNetInputGrad(torch.autograd.Function):
+    """Scores with the gradient w.r.t. the input spectrogram formed by the HIP library (white_box_attack.py:392,437-439)."""
+
+    @staticmethod
+    def forward(ctx, x, net):
+        with torch.no_grad():
+            out, bufs = net._run(x.detach())
+        ctx.net, ctx.bufs = net, bufs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.no_grad():
+            dx = ctx.net._input_grad(ctx.bufs, g.detach().float().contiguous())
+        ctx.bufs = None
+        return dx, None
+
+
 class NativeConvNet(nn.Module):
     """``NativeConvNet(module)(x)`` == ``module.eval()(x)`` for the reference's 2-D classifiers, computed by the HIP
     library.  The wrapped module keeps owning the parameters (``.module``); call ``refresh()`` after changing them."""
@@ -367,7 +385,11 @@ class NativeConvNet(nn.Module):
         if self.training:
             raise NotImplementedError("NativeConvNet: inference only (BatchNorm folded); call .eval()")
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("NativeConvNet: forward-only HIP path; autograd through it is not implemented")
+            return _ConvNetInputGrad.apply(x, self)              # white-box attack: dL/dx (parameters frozen)
+        return self._run(x)[0]
+
+    def _run(self, x):
+        """-> (output, every buffer of the plan) -- the backward pass needs the intermediate activations."""
         if x.dim() != 4 or tuple(x.shape[1:]) != self.input_chw:
             raise ValueError(f"expected [B, {self.input_chw}], got {tuple(x.shape)}")
         if not x.is_cuda:
@@ -416,4 +438,110 @@ class NativeConvNet(nn.Module):
         o = self.plan.output
         out = buf(o)
         assert o.full
-        return out.view(B, -1) if (o.H == 1 and o.W == 1) else out
+        return (out.view(B, -1) if (o.H == 1 and o.W == 1) else out), bufs
+
+    # ---- input gradient (SURVEY section 8 f-1 for the spectrogram classifiers) ------------------------------------
+    def _prepare_backward(self):
+        """Per conv step: the flipped, transposed weights (BatchNorm scale folded in) packed for ap_conv2d_fwd."""
+        lib, W, dev = N.lib(), self._dev_weights, self._dev
+        packs = {}
+        for i, st in enumerate(self.plan.steps):
+            if st.kind != "conv":
+                continue
+            w = W[st.p["wk"]]
+            if st.p["sk"]:
+                w = w * W[st.p["sk"]].reshape(-1, 1, 1, 1)
+            Cout, Cg, kh, kw = w.shape
+            g = st.p["groups"]
+            # [g][Cout/g][Cin/g][kh][kw] -> [g][Cin/g][Cout/g][kh][kw], taps flipped: conv from Cout to Cin, same groups
+            wt = w.reshape(g, Cout // g, Cg, kh, kw).permute(0, 2, 1, 3, 4).flip(3, 4).reshape(g * Cg, Cout // g, kh, kw).contiguous()
+            out = torch.empty(lib.ap_conv2d_packed_elems(g * Cg, Cout // g, kh, kw, g), device=dev, dtype=torch.float32)
+            N.check(lib.ap_conv2d_pack(N.ptr(wt), None, N.ptr(out), g * Cg, Cout // g, kh, kw, g, N.stream()), "ap_conv2d_pack")
+            packs[i] = out
+        torch.cuda.synchronize(dev)
+        self._bwd_packed = packs
+
+    def _input_grad(self, bufs, dout):
+        """Reverse sweep over the plan: every step adds its contribution into the gradient buffers of its inputs."""
+        if getattr(self, "_bwd_packed", None) is None or self._bwd_key is not self._dev_weights:
+            self._prepare_backward()
+            self._bwd_key = self._dev_weights
+        lib, W, st_ = N.lib(), self._dev_weights, N.stream()
+        plan = self.plan
+        B, dev = dout.shape[0], dout.device
+        grads = {}
+
+        def gbuf(b):
+            if b not in grads:
+                C_, H_, W_ = plan.buf_shape[b]
+                grads[b] = torch.zeros((B, C_, H_, W_), device=dev, dtype=torch.float32)
+            return grads[b]
+
+        def acc(src, C_, HW, s_cs, s_co, v):                      # g[v] += src[:, s_co : s_co + C]
+            N.check(lib.ap_acc_channels(N.ptr(src), N.ptr(gbuf(v.buf)), B, C_, HW, s_cs, s_co, v.cstride, v.coff, st_),
+                    "ap_acc_channels")
+
+        def masked(o, relu):                                     # incoming gradient of a full output, through its ReLU
+            dy = gbuf(o.buf)
+            if not relu:
+                return dy
+            out = torch.empty_like(dy)
+            N.check(lib.ap_relu_mask(N.ptr(dy), N.ptr(bufs[o.buf]), N.ptr(out), dy.numel(), st_), "ap_relu_mask")
+            return out
+
+        o = plan.output
+        gbuf(o.buf).copy_(dout.reshape(B, o.C, o.H, o.W))
+        for i in range(len(plan.steps) - 1, -1, -1):
+            s = plan.steps[i]
+            o, p = s.out, s.p
+            if o.buf not in grads:                               # nothing downstream used this value
+                continue
+            if s.kind == "conv":
+                v = s.ins[0]
+                dy = masked(o, p["relu"])
+                if p["res"] is not None:
+                    acc(dy, o.C, o.H * o.W, o.C, 0, p["res"])
+                k, sd, pad = p["kh"], p["stride"], p["pad"]
+                assert p["kh"] == p["kw"] and pad <= k - 1
+                src, Hs, Ws = dy, o.H, o.W
+                if sd > 1:
+                    Hs = (o.H - 1) * sd + 1 + (v.H + 2 * pad - k) % sd
+                    Ws = (o.W - 1) * sd + 1 + (v.W + 2 * pad - k) % sd
+                    src = torch.empty((B, o.C, Hs, Ws), device=dev, dtype=torch.float32)
+                    N.check(lib.ap_zero_insert2d(N.ptr(dy), N.ptr(src), B * o.C, o.H, o.W, Hs, Ws, sd, st_), "ap_zero_insert2d")
+                tmp = torch.empty((B, v.C, v.H, v.W), device=dev, dtype=torch.float32)
+                assert Hs + 2 * (k - 1 - pad) - k + 1 == v.H and Ws + 2 * (k - 1 - pad) - k + 1 == v.W
+                N.check(lib.ap_conv2d_fwd(N.ptr(src), N.ptr(self._bwd_packed[i]), None, None, N.ptr(tmp), B, o.C, Hs, Ws, v.C, k, k,
+                                          1, k - 1 - pad, p["groups"], self._conv_flags, o.C, 0, st_), "ap_conv2d_fwd")
+                acc(tmp, v.C, v.H * v.W, v.C, 0, v)
+            elif s.kind == "affine":
+                v = s.ins[0]
+                dy = masked(o, p["relu"])
+                if p["sk"]:
+                    tmp = torch.empty_like(dy)
+                    zero = self._zeros(o.C, dev)
+                    N.check(lib.ap_affine_nchw(N.ptr(dy), N.ptr(W[p["sk"]]), N.ptr(zero), N.ptr(tmp), B, o.C, o.H * o.W, o.C, 0, 0,
+                                               st_), "ap_affine_nchw")
+                    dy = tmp
+                acc(dy, o.C, o.H * o.W, o.C, 0, v)
+            elif s.kind == "add":
+                dy = masked(o, p["relu"])
+                for v in s.ins:
+                    acc(dy, o.C, o.H * o.W, o.C, 0, v)
+            elif s.kind == "copy":
+                v = s.ins[0]
+                acc(gbuf(o.buf), v.C, v.H * v.W, o.cstride, o.coff, v)
+            elif s.kind == "pool":
+                v = s.ins[0]
+                assert v.full and o.full
+                tmp = torch.empty((B, v.C, v.H, v.W), device=dev, dtype=torch.float32)
+                N.check(lib.ap_pool2d_bwd(N.ptr(bufs[v.buf]), N.ptr(gbuf(o.buf)), N.ptr(tmp), B * v.C, v.H, v.W, p["k"], p["stride"],
+                                          p["pad"], int(p["is_max"]), st_), "ap_pool2d_bwd")
+                acc(tmp, v.C, v.H * v.W, v.C, 0, v)
+        return gbuf(plan.input.buf)
+
+    def _zeros(self, n, dev):
+        z = getattr(self, "_zero_vec", None)
+        if z is None or z.numel() < n or z.device != dev:
+            self._zero_vec = z = torch.zeros(max(n, 4096), device=dev)
+        return z

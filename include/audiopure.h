@@ -306,6 +306,15 @@ int ap_nes_grad(const float *loss, float *grad, uint64_t seed, uint32_t draw, in
                 void *stream);
 /* counts[argmax_k scores[b][k]] += 1 for b < B (int64 device histogram; certified_robust.py:58-65) */
 int ap_argmax_hist(const float *scores, long long *counts, int B, int K, void *stream);
+/* pieces of the input gradient of the lowered 2-D classifiers (audiopure_amd/convnet.py): slice accumulate, backward
+ * through a fused ReLU, zero insertion for the transposed conv of a strided conv (the conv itself is ap_conv2d_fwd on
+ * the flipped, transposed weights), pooling backward. */
+int ap_acc_channels(const float *src, float *dst, int B, int C, int HW, int s_cstride, int s_coff, int d_cstride, int d_coff,
+                    void *stream);
+int ap_relu_mask(const float *dy, const float *y, float *out, size_t n, void *stream);
+int ap_zero_insert2d(const float *dy, float *out, int BC, int Ho, int Wo, int Hz, int Wz, int stride, void *stream);
+int ap_pool2d_bwd(const float *x, const float *dy, float *dx, int BC, int H, int W, int k, int stride, int pad, int is_max,
+                  void *stream);
 /* mode-0 ap_melspec_db backward with respect to the waveform: dout [B][n_mels][F] -> dx [B][1][L]; scratch: B F 2048 floats */
 int ap_melspec_db_bwd(const float *x, const float *dout, float *dx, float *scratch, int n_mels, int B, int L, void *stream);
 /* M5.forward (M5Net.py:20-38) backward with respect to the waveform: dlogprobs [B][n_output] -> dx [B][1][L] */
