@@ -307,3 +307,51 @@ def test_white_box_gradient_through_mel_and_spectrogram_classifier(dev):
     fd = (lp - lm).item() / (2 * eps)
     an = float((g * d).sum())
     assert abs(fd - an) < 0.15 * abs(an) + 1e-3, (fd, an)
+
+
+class _CatSliceNet(torch.nn.Module):
+    """DenseNet / DPN-style plumbing in miniature: torch.cat, channel slices feeding different consumers, a value used
+    twice, grouped stride-2 conv, 1x1 convs, avg- and max-pool with padding, BatchNorm without a preceding conv."""
+
+    def __init__(self):
+        super().__init__()
+        nn = torch.nn
+        self.c1 = nn.Conv2d(1, 24, 3, padding=1, bias=False)
+        self.b1 = nn.BatchNorm2d(24)
+        self.c2 = nn.Conv2d(24, 16, 3, padding=1, bias=True)
+        self.b2 = nn.BatchNorm2d(40)
+        self.c3 = nn.Conv2d(40, 32, 3, stride=2, padding=1, groups=4, bias=False)
+        self.b3 = nn.BatchNorm2d(32)
+        self.c4 = nn.Conv2d(16, 16, 1, bias=False)
+        self.c5 = nn.Conv2d(32, 48, 3, stride=2, padding=1, bias=False)
+        self.fc = nn.Linear(48, 10)
+
+    def forward(self, x):
+        import torch.nn.functional as F
+        a = F.relu(self.b1(self.c1(x)))
+        b = self.c2(a)
+        cat = torch.cat([a, b], 1)                                   # 40 channels
+        d = F.relu(self.b3(self.c3(F.relu(self.b2(cat)))))           # 32 @ 16x16
+        e = torch.cat([d[:, :16] + self.c4(d[:, 16:]), d[:, 16:]], 1)
+        f = F.max_pool2d(e, 3, stride=2, padding=1)                  # 32 @ 8x8
+        g = F.relu(self.c5(f))                                       # 48 @ 4x4
+        h = F.avg_pool2d(g, 4)
+        return self.fc(h.view(h.size(0), -1))
+
+
+def test_convnet_backward_covers_cat_slices_and_pools(dev):
+    from audiopure_amd.audio_models.convnets import synth_init
+    from audiopure_amd.convnet import NativeConvNet
+    mod = synth_init(_CatSliceNet(), 9).eval()
+    net = NativeConvNet(mod).eval()
+    x = torch.from_numpy(synth.uniform("csn", (3, 1, 32, 32), 1, -2.0, 2.0))
+    v = torch.from_numpy(synth.uniform("csnv", (3, 10), 1, -1.0, 1.0))
+    xr = x.clone().requires_grad_(True)
+    out_ref = mod(xr)
+    (g_ref,) = torch.autograd.grad(out_ref, xr, v)
+    xd = x.to(dev).requires_grad_(True)
+    out = net(xd)
+    assert rel_err(out.detach().cpu().numpy(), out_ref.detach().numpy()) < 1e-5
+    (g,) = torch.autograd.grad(out, xd, v.to(dev))
+    d = np.abs(g.cpu().numpy() - g_ref.numpy()) / float(np.abs(g_ref.numpy()).max())
+    assert d.max() < 2e-2 and np.median(d) < 1e-5, (d.max(), np.median(d))
