@@ -69,6 +69,9 @@ SIGNATURES = {
     "ap_kws_destroy": (_i, [_vp]),
     "ap_kws_fwd": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_melspec_db_htk": (_i, [_fp, _fp, _i, _i, _i, _vp]),
+    "ap_kws_bwd_scratch_elems": (C.c_size_t, [_vp, _i, _i]),
+    "ap_kws_bwd": (_i, [_vp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
+    "ap_melspec_db_htk_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_nes_perturb": (_i, [_fp, _fp, _f, _u64, _u32, _i, _i, _i, _i, _vp]),
     "ap_nes_grad": (_i, [_fp, _fp, _u64, _u32, _i, _i, _i, _i, _vp]),
     "ap_argmax_hist": (_i, [_fp, _vp, _i, _i, _vp]),

@@ -38,6 +38,30 @@ class _ApplyAttn(nn.Module):
         self.U = nn.Linear(in_size, num_classes, bias=False)
 
 
+class _KwsInputGrad(torch.autograd.Function):
+    """log-probabilities with a gradient with respect to the mel input only (parameters are frozen at evaluation)."""
+
+    @staticmethod
+    def forward(ctx, x, model):
+        h = model._handle()
+        xc = x.detach().float().contiguous()
+        out = torch.empty((xc.shape[0], model.num_classes), device=xc.device, dtype=torch.float32)
+        N.check(N.lib().ap_kws_fwd(h, N.ptr(xc), N.ptr(out), xc.shape[0], xc.shape[2], N.stream()), "ap_kws_fwd")
+        ctx.model, ctx.x = model, xc
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        model, xc = ctx.model, ctx.x
+        h = model._handle()
+        B, _, T = xc.shape
+        g = g.detach().float().contiguous()
+        dx = torch.empty_like(xc)
+        scr = torch.empty(N.lib().ap_kws_bwd_scratch_elems(h, B, T), device=xc.device, dtype=torch.float32)
+        N.check(N.lib().ap_kws_bwd(h, N.ptr(xc), N.ptr(g), N.ptr(dx), N.ptr(scr), B, T, N.stream()), "ap_kws_bwd")
+        return dx, None
+
+
 class KWSModel(nn.Module):
 
     def __init__(self, in_size=40, hidden_size=64, kernel_size=(20, 5), stride=(8, 2), gru_num_layers=2, num_dirs=2,
@@ -85,11 +109,11 @@ class KWSModel(nn.Module):
         if hidden is not None:
             raise NotImplementedError("audiopure_amd KWSModel: a caller-supplied initial GRU state is not built "
                                       "(the scripts pass none, model.py:99-100)")
-        if torch.is_grad_enabled() and batch.requires_grad:
-            raise NotImplementedError("audiopure_amd KWSModel: forward-only HIP path")
         x = batch.squeeze(1) if batch.ndim == 4 else batch
         if x.ndim != 3 or x.shape[1] != self.in_size:
             raise ValueError(f"expected [B,1,{self.in_size},T], got {tuple(batch.shape)}")
+        if torch.is_grad_enabled() and x.requires_grad and x.shape[0] > 0:
+            return _KwsInputGrad.apply(x.float(), self)          # white-box attack: d/d(mel) on the device (ap_kws_bwd)
         h = self._handle()
         x = x.detach().float().contiguous()
         out = torch.empty((x.shape[0], self.num_classes), device=x.device, dtype=torch.float32)

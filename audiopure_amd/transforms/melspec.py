@@ -61,6 +61,28 @@ class ToMelSpectrogramDB(MelSpecDB):
     mode = 1
 
 
+class _MelHTKGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xf, n_mels):
+        xc = xf.detach().float().contiguous()
+        B, L = xc.shape
+        out = torch.empty((B, n_mels, 1 + L // 200), device=xc.device, dtype=torch.float32)
+        N.check(N.lib().ap_melspec_db_htk(N.ptr(xc), N.ptr(out), n_mels, B, L, N.stream()), "ap_melspec_db_htk")
+        ctx.x, ctx.n_mels = xc, n_mels
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xc = ctx.x
+        B, L = xc.shape
+        g = g.detach().float().contiguous()
+        dx = torch.empty_like(xc)
+        scr = torch.empty(B * (1 + L // 200) * 400, device=xc.device, dtype=torch.float32)
+        N.check(N.lib().ap_melspec_db_htk_bwd(N.ptr(xc), N.ptr(g), N.ptr(dx), N.ptr(scr), ctx.n_mels, B, L, N.stream()),
+                "ap_melspec_db_htk_bwd")
+        return dx, None
+
+
 class MelSpecDBHTK(torch.nn.Module):
     """The KWS script's front-end (kws_adaptive_attack_eval.py:65-67): torchaudio ``MelSpectrogram(sample_rate=16000,
     n_mels)`` with its defaults (n_fft = win = 400, hop = 200, reflect padding, HTK mel scale, no filter norm) followed
@@ -71,10 +93,10 @@ class MelSpecDBHTK(torch.nn.Module):
         self.n_mels = n_mels
 
     def forward(self, x):
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("audiopure_amd MelSpecDBHTK: forward-only HIP path")
         lead = x.shape[:-1]
         L = x.shape[-1]
+        if torch.is_grad_enabled() and x.requires_grad and x.numel() > 0:
+            return _MelHTKGrad.apply(x.float().reshape(-1, L), self.n_mels).reshape(*lead, self.n_mels, 1 + L // 200)
         xf = x.detach().float().reshape(-1, L).contiguous()
         B = xf.shape[0]
         frames = 1 + L // 200

@@ -288,6 +288,13 @@ int ap_kws_create(int n_mels, int hidden, int num_classes, const float *blob_dev
 int ap_kws_destroy(ap_kws *k);
 int ap_kws_fwd(ap_kws *k, const float *mel, float *logprobs, int B, int T, void *stream);
 int ap_melspec_db_htk(const float *x, float *out, int n_mels, int B, int L, void *stream);
+/* Input gradients of the two above (the script's default attack is PGD through front-end + classifier,
+ * kws_adaptive_attack_eval.py:132-143).  ap_kws_bwd: dlogprobs [B][K] -> dmel [B][n_mels][T]; `scratch` holds
+ * ap_kws_bwd_scratch_elems floats (the recomputed GRU gates).  ap_melspec_db_htk_bwd: dout [B][n_mels][1 + L/200] ->
+ * dx [B][L]; `scratch` holds B * (1 + L/200) * 400 floats. */
+size_t ap_kws_bwd_scratch_elems(const ap_kws *k, int B, int T);
+int ap_kws_bwd(ap_kws *k, const float *mel, const float *dlogprobs, float *dmel, float *scratch, int B, int T, void *stream);
+int ap_melspec_db_htk_bwd(const float *x, const float *dout, float *dx, float *scratch, int n_mels, int B, int L, void *stream);
 
 /* ---- input gradient of the eps-network (reference: the white-box attack back-propagates through
  * the defender, robustness_eval/white_box_attack.py:392,437-439; diffwave_sde.py:200-204 sdeint_adjoint).  The GEMM-shaped

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 def kws_forward(sd: dict, x: torch.Tensor, hidden: int = 64, stride=(8, 2), kernel=(20, 5)) -> torch.Tensor:
     """x: [B,1,n_mels,T] or [B,n_mels,T] mel-dB -> log-probabilities [B,num_classes] (model.py:92-114)."""
-    t = {k: (torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v).float() for k, v in sd.items()}
+    t = {k: (torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v).to(x.dtype) for k, v in sd.items()}
     x = x.squeeze(1) if x.ndim == 4 else x
     n_in = x.shape[1]
     h = F.conv1d(x, t["CRNN_model.sepconv.0.weight"], t["CRNN_model.sepconv.0.bias"], stride=stride[1], groups=n_in)   # :7-9
@@ -30,7 +30,7 @@ def kws_forward(sd: dict, x: torch.Tensor, hidden: int = 64, stride=(8, 2), kern
         for suffix, order in (("", range(seq.shape[0])), ("_reverse", range(seq.shape[0] - 1, -1, -1))):
             wi, wh = t[f"CRNN_model.gru.weight_ih_l{layer}{suffix}"], t[f"CRNN_model.gru.weight_hh_l{layer}{suffix}"]
             bi, bh = t[f"CRNN_model.gru.bias_ih_l{layer}{suffix}"], t[f"CRNN_model.gru.bias_hh_l{layer}{suffix}"]
-            hs = torch.zeros(seq.shape[1], H)                           # hidden=None -> zeros (:99-100)
+            hs = torch.zeros(seq.shape[1], H, dtype=x.dtype)                         # hidden=None -> zeros (:99-100)
             out = [None] * seq.shape[0]
             for s in order:
                 gi, gh = seq[s] @ wi.t() + bi, hs @ wh.t() + bh
