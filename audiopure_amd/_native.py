@@ -96,6 +96,9 @@ SIGNATURES = {
     "ap_silu": (_i, [_fp, _fp, _sz, _vp]),
     "ap_upsample_nearest2x": (_i, [_fp, _fp, _i, _i, _i, _vp]),
     "ap_attention_qkv": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_groupnorm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _f, _i, _vp]),
+    "ap_attention_qkv_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "ap_upsample_nearest2x_bwd": (_i, [_fp, _fp, _i, _i, _i, _vp]),
     "ap_axpbyc": (_i, [_fp, _fp, _fp, _f, _f, _f, _sz, _vp]),
     "ap_psample_update": (_i, [_fp, _fp, _fp, _fp, _f, _f, _f, _f, _f, _i, _sz, _vp]),
     "ap_philox_normal": (_i, [_fp, _u64, _u32, _u64, _i, _i, _vp]),

@@ -72,7 +72,7 @@ class RevImprovedDiffusion(torch.nn.Module):
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim
         if torch.is_grad_enabled() and img.requires_grad:
-            raise NotImplementedError("audiopure_amd RevImprovedDiffusion: forward-only HIP path")
+            return self._differentiable_sample(img)
         lib = N.lib()
         img = img.detach().to(self.device).float().contiguous()
         B, n = img.shape[0], img.numel()
@@ -102,6 +102,36 @@ class RevImprovedDiffusion(torch.nn.Module):
                 N.check(lib.ap_axpbyc(N.ptr(x), None, N.ptr(out), 1.0 / k, 0.0, 1.0 / k + MEL_LOWER_BOUND, n, st()))
                 xs.append(out)
                 x0 = out                                # the reference feeds the de-standardised result back (:206-209)
+        return torch.cat(xs, dim=0)
+
+    def _differentiable_sample(self, img):
+        """The same sampler as an autograd graph (white-box attack through the DiffSpec defense): the chain of Euler
+        links is one node whose backward recomputes each link's UNet evaluation and applies its J^T on the HIP path
+        (``_grad._ChainFn`` + ``UNetModel.input_grad``); the affine (de)standardisation is ordinary autograd."""
+        from ._grad import _ChainFn
+        from .improved_diffusion_unet import UNetEpsGrad
+        if not hasattr(self.model, "_eps_grad"):
+            self.model._eps_grad = UNetEpsGrad(self.model)
+        k = 2.0 / (MEL_UPPER_BOUND - MEL_LOWER_BOUND)
+        x0 = img.to(self.device).float() * k + (-MEL_LOWER_BOUND * k - 1.0)
+        xs = []
+        for it in range(self.args.sample_step):
+            total = self.args.t
+            if self.args.rand_t:
+                total = self.args.t + np.random.randint(-self.args.t_delta, self.args.t_delta)
+                print(f'total_noise_levels: {total}')
+            betas = torch.linspace(0.1 / 1000, 20.0 / 1000, 1000)
+            a = float((1 - betas).cumprod(dim=0)[total - 1].double())
+            table = sde_step_table(self.args.t)
+            zs = [self._z(x0.detach())]
+            steps = []
+            for i, (disc, ca, cb, cs) in enumerate(table):
+                zs.append(self._z(x0.detach()))
+                steps.append((disc, ca, cb, cs, i + 1))
+            x = _ChainFn.apply(x0, self.model._eps_grad, steps, math.sqrt(a), math.sqrt(1.0 - a), zs)
+            out = x * (1.0 / k) + (1.0 / k + MEL_LOWER_BOUND)
+            xs.append(out)
+            x0 = out
         return torch.cat(xs, dim=0)
 
     def forward(self, x):

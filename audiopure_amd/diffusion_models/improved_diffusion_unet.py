@@ -94,6 +94,7 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(nn.Sequential(*layers))
         self.out = nn.Sequential(nn.GroupNorm(32, ch), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
         self._packed, self._key = None, None
+        self._packed_t, self._tape = {}, None
         half = model_channels // 2                                        # nn.py:113-116, as the reference computes them
         self.register_buffer("_freqs", torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half),
                              persistent=False)
@@ -120,6 +121,7 @@ class UNetModel(nn.Module):
                              (m.stride[0] if hasattr(m, "stride") else 1), (m.padding[0] if hasattr(m, "padding") else 0))
         torch.cuda.synchronize(dev)
         self._packed, self._key = packed, key
+        self._packed_t = {}                                # transposed images for the input gradient, built on first use
 
     def set_precision(self, mode: str):
         """"f32": fp32 MFMA convolutions (default); "f32s": the bf16 MFMA with exactly 3-way-split fp32 operands
@@ -127,12 +129,14 @@ class UNetModel(nn.Module):
         self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100}[mode]
         return self
 
-    def _conv(self, m, x, B, Cin, H, W, res=None):
+    def _conv(self, m, x, B, Cin, H, W, res=None, track=True):
         wT, bias, cout, kh, kw, stride, pad = self._packed[m]
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         out = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
         N.check(N.lib().ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, H, W, cout, kh, kw, stride,
                                       pad, 1, getattr(self, "_conv_flags", 0), Cin, 0, N.stream()), "ap_conv2d_fwd")
+        if track and self._tape is not None:
+            self._tape.append(("conv", m, x, res, out, (B, Cin, H, W)))
         return out
 
     def _gn(self, gn, x, ss=None, act=2):
@@ -140,12 +144,14 @@ class UNetModel(nn.Module):
         y = torch.empty_like(x)
         N.check(N.lib().ap_groupnorm_nchw(N.ptr(x), N.ptr(gn.weight.detach()), N.ptr(gn.bias.detach()), N.ptr(ss), N.ptr(y), B, C_,
                                           H * W, gn.num_groups, float(gn.eps), act, N.stream()), "ap_groupnorm_nchw")
+        if self._tape is not None:
+            self._tape.append(("gn", gn, x, ss, act, y))
         return y
 
     def _resblock(self, rb, x, emb_silu):
         B, C_, H, W = x.shape
         h = self._conv(rb.in_layers[2], self._gn(rb.in_layers[0], x), B, C_, H, W)                 # unet.py:181
-        ss = self._conv(rb.emb_layers[1], emb_silu, B, emb_silu.shape[1], 1, 1).view(B, -1)        # :182 (SiLU applied once)
+        ss = self._conv(rb.emb_layers[1], emb_silu, B, emb_silu.shape[1], 1, 1, track=False).view(B, -1)   # :182 (SiLU applied once)
         h = self._gn(rb.out_layers[0], h, ss=ss)                                                   # :186-190 (+ SiLU)
         skip = x if isinstance(rb.skip_connection, nn.Identity) else self._conv(rb.skip_connection, x, B, C_, H, W)
         return self._conv(rb.out_layers[3], h, B, rb.out_channels, H, W, res=skip)                 # :194
@@ -155,6 +161,8 @@ class UNetModel(nn.Module):
         qkv = self._conv(ab.qkv, self._gn(ab.norm, x, act=0), B, C_, H, W)                         # unet.py:229-230
         att = torch.empty_like(x)
         N.check(N.lib().ap_attention_qkv(N.ptr(qkv), N.ptr(att), B, C_, H * W, ab.num_heads, N.stream()), "ap_attention_qkv")
+        if self._tape is not None:
+            self._tape.append(("attn", qkv, att, ab.num_heads))
         return self._conv(ab.proj_out, att, B, C_, H, W, res=x)                                    # :234-235
 
     def _run(self, seq, h, emb_silu):
@@ -169,6 +177,8 @@ class UNetModel(nn.Module):
             elif isinstance(layer, Upsample):
                 up = torch.empty((B, C_, 2 * H, 2 * W), device=h.device, dtype=torch.float32)
                 N.check(N.lib().ap_upsample_nearest2x(N.ptr(h), N.ptr(up), B * C_, H, W, N.stream()), "ap_upsample_nearest2x")
+                if self._tape is not None:
+                    self._tape.append(("up", h, up))
                 h = self._conv(layer.conv, up, B, C_, 2 * H, 2 * W)
             elif isinstance(layer, nn.Conv2d):
                 h = self._conv(layer, h, B, C_, H, W)
@@ -179,20 +189,34 @@ class UNetModel(nn.Module):
     def forward(self, x, timesteps, y=None):
         assert y is None, "class conditioning is not built"
         if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError("audiopure_amd UNetModel: forward-only HIP path; autograd through it is not implemented")
+            return _UNetInputGrad.apply(x, self, timesteps)       # white-box attack: d/dx on the HIP path (input_grad)
+        return self._forward(x, timesteps)
+
+    def forward_save(self, x, timesteps):
+        """One evaluation that also records what its input gradient needs: (eps, tape)."""
+        self._tape = []
+        try:
+            out = self._forward(x, timesteps)
+            return out, self._tape
+        finally:
+            self._tape = None
+
+    def _forward(self, x, timesteps):
         self._prepare()
         lib = N.lib()
         x = x.detach().float().contiguous()
         B, dev = x.shape[0], x.device
+        if self._tape is not None:
+            self._tape.append(("in", x))
         t = timesteps.detach().to(dev).float().reshape(-1).contiguous()
         if t.numel() == 1 and B > 1:
             t = t.expand(B).contiguous()
         temb = torch.empty((B, self.model_channels), device=dev, dtype=torch.float32)
         N.check(lib.ap_timestep_embedding(N.ptr(t), N.ptr(self._freqs), N.ptr(temb), B, self.model_channels, N.stream()))
-        e = self._conv(self.time_embed[0], temb, B, self.model_channels, 1, 1).view(B, -1)
+        e = self._conv(self.time_embed[0], temb, B, self.model_channels, 1, 1, track=False).view(B, -1)
         e_s = torch.empty_like(e)
         N.check(lib.ap_silu(N.ptr(e), N.ptr(e_s), e.numel(), N.stream()))
-        emb = self._conv(self.time_embed[2], e_s, B, e.shape[1], 1, 1).view(B, -1)                 # unet.py:479
+        emb = self._conv(self.time_embed[2], e_s, B, e.shape[1], 1, 1, track=False).view(B, -1)    # unet.py:479
         emb_silu = torch.empty_like(emb)                                   # every ResBlock starts emb_layers with SiLU
         N.check(lib.ap_silu(N.ptr(emb), N.ptr(emb_silu), emb.numel(), N.stream()))
         hs, h = [], x
@@ -207,9 +231,135 @@ class UNetModel(nn.Module):
             cat = torch.empty((Bc, C1 + C2, H, W), device=dev, dtype=torch.float32)
             N.check(lib.ap_copy_channels(N.ptr(h), N.ptr(cat), Bc, C1, H * W, C1, 0, C1 + C2, 0, N.stream()))
             N.check(lib.ap_copy_channels(N.ptr(skip), N.ptr(cat), Bc, C2, H * W, C2, 0, C1 + C2, C1, N.stream()))
+            if self._tape is not None:
+                self._tape.append(("cat", h, skip, cat))
             h = self._run(blk, cat, emb_silu)
         Bc, C_, H, W = h.shape
         return self._conv(self.out[2], self._gn(self.out[0], h), Bc, C_, H, W)                     # :494
+
+    # ---- input gradient: reverse sweep over the tape of one evaluation -----------------------------------------------
+    def _conv_t(self, m):
+        """Packed image of the transposed convolution of ``m`` (spatially flipped, in/out swapped)."""
+        if m not in self._packed_t:
+            w = m.weight.detach().float()
+            if w.dim() == 3:
+                w = w[..., None]
+            wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+            co, ci, kh, kw = wt.shape
+            img = torch.empty(N.lib().ap_conv2d_packed_elems(co, ci, kh, kw, 1), device=wt.device, dtype=torch.float32)
+            N.check(N.lib().ap_conv2d_pack(N.ptr(wt), None, N.ptr(img), co, ci, kh, kw, 1, N.stream()), "ap_conv2d_pack")
+            self._packed_t[m] = img
+        return self._packed_t[m]
+
+    def input_grad(self, tape, dout):
+        """J^T dout of the evaluation ``tape`` came from (parameters and the timestep embedding are constants)."""
+        lib, st = N.lib(), N.stream
+        flags = getattr(self, "_conv_flags", 0)
+        out_t = tape[-1][4]
+        grads = {id(out_t): dout.detach().float().contiguous()}
+
+        def acc(t, g):
+            k = id(t)
+            if k in grads:
+                N.check(lib.ap_axpbyc(N.ptr(grads[k]), N.ptr(g), N.ptr(grads[k]), 1.0, 1.0, 0.0, g.numel(), st()), "ap_axpbyc")
+            else:
+                grads[k] = g
+
+        for op in reversed(tape):
+            kind = op[0]
+            if kind == "conv":
+                _, m, x, res, out, (B, Cin, H, W) = op
+                g = grads.pop(id(out), None)
+                if g is None:
+                    continue
+                _, _, cout, kh, kw, stride, pad = self._packed[m]
+                Ho, Wo = out.shape[2], out.shape[3]
+                if stride != 1:                                   # Downsample: spread dy onto the input grid first
+                    z = torch.empty((B, cout, H, W), device=g.device, dtype=torch.float32)
+                    N.check(lib.ap_zero_insert2d(N.ptr(g), N.ptr(z), B * cout, Ho, Wo, H, W, stride, st()), "ap_zero_insert2d")
+                    src, Hs, Ws = z, H, W
+                else:
+                    src, Hs, Ws = g, Ho, Wo
+                dx = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32)
+                N.check(lib.ap_conv2d_fwd(N.ptr(src), N.ptr(self._conv_t(m)), None, None, N.ptr(dx), B, cout, Hs, Ws, Cin, kh, kw, 1,
+                                          kh - 1 - pad, 1, flags, cout, 0, st()), "ap_conv2d_fwd")
+                acc(x, dx)
+                if res is not None:
+                    acc(res, g)
+            elif kind == "gn":
+                _, gn, x, ss, act, y = op
+                g = grads.pop(id(y), None)
+                if g is None:
+                    continue
+                B, C_, H, W = x.shape
+                dx = torch.empty_like(x)
+                N.check(lib.ap_groupnorm_bwd(N.ptr(x), N.ptr(gn.weight.detach()), N.ptr(gn.bias.detach()), N.ptr(ss), N.ptr(g),
+                                             N.ptr(dx), B, C_, H * W, gn.num_groups, float(gn.eps), act, st()), "ap_groupnorm_bwd")
+                acc(x, dx)
+            elif kind == "attn":
+                _, qkv, att, heads = op
+                g = grads.pop(id(att), None)
+                if g is None:
+                    continue
+                B, C_, H, W = att.shape
+                dqkv = torch.empty_like(qkv)
+                stats = torch.empty(B * heads * H * W * 3, device=g.device, dtype=torch.float32)
+                N.check(lib.ap_attention_qkv_bwd(N.ptr(qkv), N.ptr(att), N.ptr(g), N.ptr(dqkv), N.ptr(stats), B, C_, H * W, heads,
+                                                 st()), "ap_attention_qkv_bwd")
+                acc(qkv, dqkv)
+            elif kind == "up":
+                _, h, up = op
+                g = grads.pop(id(up), None)
+                if g is None:
+                    continue
+                B, C_, H, W = h.shape
+                dh = torch.empty_like(h)
+                N.check(lib.ap_upsample_nearest2x_bwd(N.ptr(g), N.ptr(dh), B * C_, H, W, st()), "ap_upsample_nearest2x_bwd")
+                acc(h, dh)
+            elif kind == "cat":
+                _, h, skip, cat = op
+                g = grads.pop(id(cat), None)
+                if g is None:
+                    continue
+                B, C1, H, W = h.shape
+                C2 = skip.shape[1]
+                dh, dsk = torch.empty_like(h), torch.empty_like(skip)
+                N.check(lib.ap_copy_channels(N.ptr(g), N.ptr(dh), B, C1, H * W, C1 + C2, 0, C1, 0, st()), "ap_copy_channels")
+                N.check(lib.ap_copy_channels(N.ptr(g), N.ptr(dsk), B, C2, H * W, C1 + C2, C1, C2, 0, st()), "ap_copy_channels")
+                acc(h, dh)
+                acc(skip, dsk)
+            elif kind == "in":
+                return grads[id(op[1])]
+        raise RuntimeError("tape without an input record")
+
+
+class _UNetInputGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, model, timesteps):
+        out, tape = model.forward_save(x, timesteps)
+        ctx.model, ctx.tape = model, tape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.no_grad():
+            dx = ctx.model.input_grad(ctx.tape, g)
+        ctx.tape = None
+        return dx, None, None
+
+
+class UNetEpsGrad:
+    """The chain's view of the UNet (same interface as ``_grad.EpsGrad``): eps with a tape, and J^T v."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def forward_save(self, x, step):
+        t = torch.full((x.shape[0],), float(step), device=x.device)
+        return self.model.forward_save(x, t)
+
+    def backward(self, saved, d_eps):
+        return self.model.input_grad(saved, d_eps)
 
 
 def model_and_diffusion_defaults():

@@ -263,6 +263,15 @@ int ap_timestep_embedding(const float *t_dev, const float *freqs_dev, float *out
 int ap_silu(const float *x, float *y, size_t n, void *stream);
 int ap_upsample_nearest2x(const float *x, float *y, int BC, int H, int W, void *stream);
 int ap_attention_qkv(const float *qkv, float *out, int B, int C, int T, int heads, void *stream);
+/* Input gradients of the three above (white-box attack through the DiffSpec purifier, adaptive_attack_eval.py:102-104 +
+ * white_box_attack.py:437-439; the convolutions' input gradients are ap_conv2d_fwd on flipped / transposed weights).
+ * ap_groupnorm_bwd: x and the forward's parameters + dy -> dx.  ap_attention_qkv_bwd: qkv, the forward's `out`, dout ->
+ * dqkv (same layout as qkv); `stats` holds B * heads * T * 3 floats.  ap_upsample_nearest2x_bwd: dy [BC][2H][2W] -> dx. */
+int ap_groupnorm_bwd(const float *x, const float *gamma, const float *beta, const float *scale_shift, const float *dy,
+                     float *dx, int B, int C, int HW, int groups, float eps, int act, void *stream);
+int ap_attention_qkv_bwd(const float *qkv, const float *out, const float *dout, float *dqkv, float *stats, int B, int C,
+                         int T, int heads, void *stream);
+int ap_upsample_nearest2x_bwd(const float *dy, float *dx, int BC, int H, int W, void *stream);
 /* out = a*x + b*y + c elementwise (y may be NULL): melspec_standardize / inv (sc09_spectrogram_dataset.py:65-81) and the
  * Euler links of the spectrogram SDE (improved_diffusion_sde.py:173-221). */
 int ap_axpbyc(const float *x, const float *y, float *out, float a, float b, float c, size_t n, void *stream);

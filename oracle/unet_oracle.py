@@ -63,8 +63,9 @@ def _run(seq, h, emb):
     return h
 
 
-def unet_forward(model, x, timesteps):
-    with torch.no_grad():
+def unet_forward(model, x, timesteps, grad=False):
+    """grad=True keeps the autograd graph (tests take the reference input gradient from it)."""
+    with torch.set_grad_enabled(grad):
         emb = model.time_embed[2](_silu(model.time_embed[0](timestep_embedding(timesteps, model.model_channels))))
         hs, h = [], x.float()
         for blk in model.input_blocks:
@@ -88,13 +89,13 @@ def melspec_inv_standardize(x):
     return (x + 1) * (MEL_UPPER_BOUND - MEL_LOWER_BOUND) / 2 + MEL_LOWER_BOUND          # :74-81
 
 
-def sde_f_g(model, x, tau, beta_min=0.1, beta_max=20.0, N=1000):
+def sde_f_g(model, x, tau, beta_min=0.1, beta_max=20.0, N=1000, grad=False):
     """f, g of the reverse SDE in torchsde time at reference time tau = 1 - s (scalar float tensor)."""
     beta_t = beta_min + tau * (beta_max - beta_min)                                      # :86
     drift = -0.5 * beta_t * x
     diffusion = torch.sqrt(beta_t)
     disc = (tau.float() * N).long()                                                      # :82-83
-    eps = unet_forward(model, x, disc.expand(x.shape[0]))                                # :106
+    eps = unet_forward(model, x, disc.expand(x.shape[0]), grad)                          # :106
     ac = torch.exp(-0.5 * (beta_max - beta_min) * tau ** 2 - beta_min * tau)             # :74
     score = (-1.0 / torch.sqrt(1.0 - ac)) * eps                                          # :75,:111
     drift = drift - diffusion ** 2 * score                                               # :116
@@ -117,15 +118,15 @@ def sde_step_times(t_star: int, dt: float = 1e-3):
     return out
 
 
-def spec_sde_purify(model, img_db, t_star: int, noises):
+def spec_sde_purify(model, img_db, t_star: int, noises, grad=False):
     """RevImprovedDiffusion.image_editing_sample, sample_step = 1 (:173-221): mel-dB in, mel-dB out."""
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         x0 = melspec_standardize(img_db.float())
         betas = torch.linspace(0.1 / 1000, 20.0 / 1000, 1000)                            # RevVPSDE defaults, :49,:66
         a = (1 - betas).cumprod(dim=0)
         x = x0 * a[t_star - 1].sqrt() + noises[0] * (1.0 - a[t_star - 1]).sqrt()         # :188-189
         for i, (tau, h) in enumerate(sde_step_times(t_star)):
-            f, g = sde_f_g(model, x, torch.tensor(float(tau), dtype=torch.float32))
+            f, g = sde_f_g(model, x, torch.tensor(float(tau), dtype=torch.float32), grad=grad)
             x = x + f * float(h) + g * math.sqrt(float(h)) * noises[1 + i]
         return melspec_inv_standardize(x)
 

@@ -89,3 +89,120 @@ def test_ddpm_spec_purifier_matches_reference_golden(dev, gold):
     dd.set_noise_source(z)
     got = dd(img.to(dev))
     assert rel_err(got.cpu().numpy(), gold["mini/ddpm_t4"]) < 1e-4
+
+
+# ---- input gradient (white-box attack through the DiffSpec purifier) ------------------------------------------------------
+def test_backward_primitives_match_autograd(dev):
+    import torch.nn.functional as F
+    from audiopure_amd import _native as N
+    lib = N.lib()
+    for act, use_ss in ((2, True), (0, False), (2, False)):
+        x = torch.from_numpy(synth.uniform("gnx", (3, 64, 8, 8), 1, -2, 2)).requires_grad_(True)
+        g, b = torch.from_numpy(synth.uniform("gng", (64,), 1, 0.5, 1.5)), torch.from_numpy(synth.uniform("gnb", (64,), 1))
+        ss = torch.from_numpy(synth.uniform("gns", (3, 128), 1))
+        dy = torch.from_numpy(synth.uniform("gndy", (3, 64, 8, 8), 1))
+        ref = F.group_norm(x, 32, g, b, 1e-5)
+        if use_ss:
+            ref = ref * (1 + ss[:, :64, None, None]) + ss[:, 64:, None, None]
+        if act == 2:
+            ref = ref * torch.sigmoid(ref)
+        (ref * dy).sum().backward()
+        xd, gd, bd, sd_, dyd = x.detach().to(dev), g.to(dev), b.to(dev), ss.to(dev), dy.to(dev)
+        dx = torch.empty_like(xd)
+        N.check(lib.ap_groupnorm_bwd(N.ptr(xd), N.ptr(gd), N.ptr(bd), N.ptr(sd_) if use_ss else None, N.ptr(dyd), N.ptr(dx), 3, 64, 64,
+                                     32, 1e-5, act, N.stream()))
+        assert rel_err(dx.cpu().numpy(), x.grad.numpy()) < 1e-5, (act, use_ss)
+    for ch, T, heads in ((16, 256, 2), (64, 64, 4), (32, 100, 1), (64, 256, 3), (8, 17, 2)):
+        qkv = torch.from_numpy(synth.uniform(f"qkv{ch}", (2, heads * 3 * ch, T), 1, -1.5, 1.5)).requires_grad_(True)
+        do = torch.from_numpy(synth.uniform(f"do{ch}", (2, heads * ch, T), 1))
+        q, k, v = torch.split(qkv.reshape(2 * heads, 3 * ch, T), ch, dim=1)
+        w = torch.softmax(torch.einsum("bct,bcs->bts", q * ch ** -0.25, k * ch ** -0.25), dim=-1)
+        ref = torch.einsum("bts,bcs->bct", w, v).reshape(2, heads * ch, T)
+        (ref * do).sum().backward()
+        qd, od, dod = qkv.detach().to(dev), ref.detach().to(dev), do.to(dev)
+        dq = torch.empty_like(qd)
+        stats = torch.empty(2 * heads * T * 3, device=dev)
+        N.check(lib.ap_attention_qkv_bwd(N.ptr(qd), N.ptr(od), N.ptr(dod), N.ptr(dq), N.ptr(stats), 2, heads * ch, T, heads, N.stream()))
+        assert rel_err(dq.cpu().numpy(), qkv.grad.numpy()) < 1e-5, (ch, T, heads)
+    dy = torch.from_numpy(synth.uniform("updy", (6, 10, 14), 1)).to(dev)
+    dx = torch.empty((6, 5, 7), device=dev)
+    N.check(lib.ap_upsample_nearest2x_bwd(N.ptr(dy), N.ptr(dx), 6, 5, 7, N.stream()))
+    assert torch.allclose(dx, dy.reshape(6, 5, 2, 7, 2).sum(dim=(2, 4)), atol=1e-6)
+
+
+def _unet_vjp_case(dev, model_cpu, t, mode="f32", tol=2e-4):
+    from oracle import unet_oracle as U
+    x = _x()
+    v = torch.from_numpy(synth.uniform("unetv", tuple(x.shape), 3))
+    xr = x.clone().requires_grad_(True)
+    (U.unet_forward(model_cpu, xr, torch.tensor([float(t)] * x.shape[0]), grad=True) * v).sum().backward()
+    import copy
+    m = copy.deepcopy(model_cpu).to(dev).set_precision(mode)
+    xg = x.to(dev).requires_grad_(True)
+    out = m(xg, torch.tensor([float(t)] * x.shape[0]))
+    (out * v.to(dev)).sum().backward()
+    with torch.no_grad():
+        assert torch.equal(out.detach(), m(x.to(dev), torch.tensor([float(t)] * x.shape[0])))
+    err = rel_err(xg.grad.cpu().numpy(), xr.grad.numpy())
+    assert err < tol, (t, mode, err)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32s"])
+def test_mini_unet_input_gradient_matches_autograd_of_the_oracle(dev, mode):
+    for t in (0, 37, 999):
+        _unet_vjp_case(dev, mini_unet(), t, mode)
+
+
+def test_full_unet_input_gradient_matches_autograd_of_the_oracle(dev):
+    _unet_vjp_case(dev, synth_init(create_model(**model_and_diffusion_defaults()), 0), 37, tol=5e-4)
+
+
+def test_white_box_gradient_through_the_spectrogram_purifier(dev):
+    """d loss / d mel through RevImprovedDiffusion (chain of Euler links, each J^T on the HIP path) vs autograd through
+    the oracle's restatement of the same chain."""
+    from oracle import unet_oracle as U
+    args = types.SimpleNamespace(t=3, rand_t=False, t_delta=0, use_bm=False, sample_step=1, score_type="guided_diffusion")
+    img = torch.from_numpy(synth.uniform("meldb", (2, 1, 32, 32), 5, -90.0, 30.0))
+    z = [torch.from_numpy(synth.normal(f"sz{i}", (2, 1, 32, 32), 5)) for i in range(4)]
+    v = torch.from_numpy(synth.uniform("specv", (2, 1, 32, 32), 3))
+    ir = img.clone().requires_grad_(True)
+    (U.spec_sde_purify(mini_unet(), ir, 3, z, grad=True) * v).sum().backward()
+    rev = RevImprovedDiffusion.from_model(mini_unet().to(dev), args)
+    rev.set_noise_source(z)
+    ig = img.to(dev).requires_grad_(True)
+    out = rev(ig)
+    (out * v.to(dev)).sum().backward()
+    rev.set_noise_source(z)
+    with torch.no_grad():
+        assert rel_err(out.detach().cpu().numpy(), rev(img.to(dev)).cpu().numpy()) < 1e-6
+    assert rel_err(ig.grad.cpu().numpy(), ir.grad.numpy()) < 5e-4
+
+
+def test_white_box_loss_gradient_end_to_end_with_the_diffspec_defense(dev):
+    """adaptive_attack_eval.py --defense DiffSpec --attack PGD: cross_entropy(AcousticSystem(ResNeXt, mel32,
+    RevImprovedDiffusion, 'spec')(x), y).backward() on the HIP path, checked by a central difference of the native loss."""
+    import torch.nn.functional as F
+    from audiopure_amd.audio_models.convnets import CifarResNeXt
+    from audiopure_amd.convnet import NativeConvNet
+    from audiopure_amd.transforms import MelSpecDB
+    from audiopure_amd.acoustic_system import AcousticSystem
+    args = types.SimpleNamespace(t=2, rand_t=False, t_delta=0, use_bm=False, sample_step=1, score_type="guided_diffusion")
+    rev = RevImprovedDiffusion.from_model(mini_unet().to(dev), args)
+    clf = NativeConvNet(synth_init(CifarResNeXt(10), 1).eval()).eval()
+    system = AcousticSystem(classifier=clf, transform=MelSpecDB(32), defender=rev, defense_type="spec")
+    x = torch.from_numpy(synth.waveforms(2, 16000, seed=14)).to(dev)
+    y = torch.tensor([1, 8], device=dev)
+    z = [torch.from_numpy(synth.normal(f"sz{i}", (2, 1, 32, 32), 5)) for i in range(3)]
+    rev.set_noise_source(z)
+    delta = torch.zeros_like(x, requires_grad=True)
+    F.cross_entropy(system(x + delta, True), y).backward()
+    g = delta.grad
+    assert g.shape == x.shape and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    eps = 2e-4
+    with torch.no_grad():
+        d = g.sign()
+        rev.set_noise_source(z); lp = F.cross_entropy(system(x + eps * d, True), y)
+        rev.set_noise_source(z); lm = F.cross_entropy(system(x - eps * d, True), y)
+    fd = (lp - lm).item() / (2 * eps)
+    an = float((g * d).sum())
+    assert abs(fd - an) < 0.15 * abs(an) + 1e-3, (fd, an)
