@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaudiopure_hip.so")
 AP_PREC_F32 = 0
 AP_PREC_BF16 = 1
 AP_PREC_F32_SPLIT = 2
+AP_PREC_F32_SPLIT_F16 = 3
 
 
 class NativeError(RuntimeError):

@@ -64,6 +64,8 @@ struct ap_ctx {
   void *slab_bf;
   void *w1p_s, *w2p_s;      // 3-way bf16-split images (AP_PREC_F32_SPLIT), own allocation
   void *slab_s;
+  void *w1p_h, *w2p_h;      // 2-way fp16-split images (AP_PREC_F32_SPLIT_F16), own allocation
+  void *slab_h;
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
   bool profile;
@@ -94,6 +96,9 @@ int launch_pack_bf16(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st);
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
+int launch_pack_splith(ap_ctx *ctx, hipStream_t st);
+int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
+                           int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);
 int launch_m5(ap_m5 *m, const float *x, float *logprobs, int B, int L, hipStream_t st);

@@ -149,10 +149,12 @@ class WaveNet_Speech_Commands(nn.Module):
     def set_precision(self, mode: str):
         """"f32": exact fp32 MFMA (default, the reference's arithmetic).  "f32s": fp32 operands split exactly into three
         bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results, ~2x faster.
-        "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  The last two need
+        "f32h": fp32 operands carried as two fp16 parts (22 significant bits), three partial products on the fp16 MFMA,
+        fp32 accumulate -- fp32-class results, ~2x faster again.
+        "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  All but "f32" need
         res_channels = 256."""
         prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
-                "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT}[mode]
+                "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "f32h": N.AP_PREC_F32_SPLIT_F16}[mode]
         if prec != self._precision:
             self._precision = prec
             self._engine = None

@@ -63,14 +63,17 @@ def cpu_baseline(budget_s: float = 25.0):
 
 
 PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16",
-             "f32s": "fp32 via exact 3-way bf16 operand split, 6 partial products on the bf16 MFMA, fp32 accumulate"}
+             "f32s": "fp32 via exact 3-way bf16 operand split, 6 partial products on the bf16 MFMA, fp32 accumulate",
+             "f32h": "fp32 operands as two fp16 parts (22 significant bits, exact power-of-two scaling), 3 partial products "
+                     "on the fp16 MFMA, fp32 accumulate"}
 
 
 def pmc_traffic(B, precision="f32"):
     """HBM-side bytes per residual-block launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 calibration, + WRITE_SIZE), scaled from the 512-clip launch it was measured on; None if absent."""
     try:
-        name = {"f32": "r1_pmc_traffic.json", "f32s": "r1_f32s_pmc_traffic.json"}.get(precision, "r1_bf16_pmc_traffic.json")
+        name = {"f32": "r1_pmc_traffic.json", "f32s": "r1_f32s_pmc_traffic.json",
+                "f32h": "r1_f32h_pmc_traffic.json"}.get(precision, "r1_bf16_pmc_traffic.json")
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         return round(d["traffic_bytes_per_launch"] * B / 512.0)
     except Exception:
@@ -85,8 +88,8 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
     ap.add_argument("--reverse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-modes", action="store_true", help="time only --precision (skip the f32s / bf16 legs)")
-    ap.add_argument("--precision", choices=["f32", "f32s", "bf16"], default="f32",
+    ap.add_argument("--no-other-modes", action="store_true", help="time only --precision (skip the f32s / f32h / bf16 legs)")
+    ap.add_argument("--precision", choices=["f32", "f32s", "f32h", "bf16"], default="f32",
                     help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     args = ap.parse_args()
@@ -190,6 +193,14 @@ def main():
                     "note": "algorithmic fp32 flops; each is 6 v_mfma_f32_32x32x16_bf16 partial products (exact 3-way "
                             "bf16 operand split, fp32 accumulate), so peak = 2500 TFLOP/s dense bf16 / 6",
                     "executed_bf16_TFLOPs": round(6 * achieved, 1)}
+        elif precision == "f32h":
+            peak = 2500.0 / 3.0                       # 3 fp16 MFMAs (same rate as bf16) per fp32 MFMA-equivalent
+            roof = {"bound": "mfma", "kernel": "resblock_f32h_kernel<256>", "achieved": round(achieved, 2),
+                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": pmc_traffic(B, "f32h"),
+                    "note": "algorithmic fp32 flops; each is 3 v_mfma_f32_32x32x16_f16 partial products (operands as two "
+                            "fp16 parts, fp32 accumulate), so peak = 2500 TFLOP/s dense fp16 / 3",
+                    "executed_f16_TFLOPs": round(3 * achieved, 1)}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "resblock_bf16_kernel<256>", "achieved": round(gbs, 1), "peak": 8000.0,
@@ -206,7 +217,7 @@ def main():
     # not the headline): same inputs, same chain, same timing brackets
     others = {}
     if world == 1 and not args.no_other_modes:
-        for prec in ("f32s", "bf16", "f32"):
+        for prec in ("f32s", "f32h", "bf16", "f32"):
             if prec == args.precision:
                 continue
             if prec == "f32" and args.precision != "f32":
@@ -226,7 +237,7 @@ def main():
             "metric": f"purified 1s@16kHz utterances/sec at {n} reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32s" else args.precision, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision in ("f32s", "f32h") else args.precision, "data": "synthetic",
             "config": {"workload": f"DiffWave {args.sampler.upper()} purify n={n} + M5 classify, batch={B}/GPU, 1 s @ 16 kHz "
                                    f"clips, {PREC_NAME[args.precision]} (BASELINE.json configs[{3 if args.precision == 'bf16' else 1}]); "
                                    "shipped config C=S=256, 36 layers",

@@ -46,9 +46,13 @@ typedef struct ap_m5 ap_m5;
 enum {
   AP_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
   AP_PREC_BF16 = 1,  /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM */
-  AP_PREC_F32_SPLIT = 2  /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
+  AP_PREC_F32_SPLIT = 2, /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
                             each product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-class results (dropped
                             terms < 2^-23 of a product) at 6/16 of the fp32 matrix instruction's time; C = 256 */
+  AP_PREC_F32_SPLIT_F16 = 3  /* fp32 operands carried as two fp16 parts (22 significant bits, exact power-of-two
+                                scaling for the exponent range), three partial products on v_mfma_f32_32x32x16_f16,
+                                fp32 accumulate: 3/16 of the fp32 instruction's time; dot-product noise between
+                                plain fp32's and AP_PREC_F32_SPLIT's; C = 256 */
 };
 
 /* configs/config.json "wavenet_config" + "diffusion_config" (reference: configs/config.json:2-17) */

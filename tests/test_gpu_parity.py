@@ -393,7 +393,7 @@ def test_split_resblock_matches_oracle_at_the_fp32_tolerance(dev, L, layer):
     hd = h.to(dev)
     pt = part_t.to(dev).contiguous()
     outs = {}
-    for mode in ("f32", "f32s"):
+    for mode in ("f32", "f32s", "f32h"):
         net.set_precision(mode)
         eng = net.engine()
         sk = skip0.to(dev).clone()
@@ -405,17 +405,19 @@ def test_split_resblock_matches_oracle_at_the_fp32_tolerance(dev, L, layer):
         N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk2), 0, B, L, N.stream()))
         assert rel_err(sk2.cpu().numpy(), s_ref.numpy()) < 5e-6, mode
         outs[mode] = (hout.cpu().numpy(), sk2.cpu().numpy())
-    assert rel_err(outs["f32s"][0], outs["f32"][0]) < 2e-6
-    assert rel_err(outs["f32s"][1], outs["f32"][1]) < 2e-6
+    for mode in ("f32s", "f32h"):
+        assert rel_err(outs[mode][0], outs["f32"][0]) < 2e-6, mode
+        assert rel_err(outs[mode][1], outs["f32"][1]) < 2e-6, mode
 
 
-def test_split_full_chain_matches_reference_golden_at_the_fp32_tolerance(golden, dev, dh):
-    """Whole shipped-config DDPM n=5 + one-shot denoise in split mode vs the reference's fp32 golden vectors, at the
+@pytest.mark.parametrize("mode", ["f32s", "f32h"])
+def test_split_full_chain_matches_reference_golden_at_the_fp32_tolerance(golden, dev, dh, mode):
+    """Whole shipped-config DDPM n=5 + one-shot denoise in the split modes vs the reference's fp32 golden vectors, at the
     tolerances the exact-fp32 tests use (TOL_CHAIN / TOL_EVAL)."""
     from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
     cfg = dict(synth.FULL_WAVENET_CONFIG)
     net, _ = _net(cfg, dev)
-    net.set_precision("f32s")
+    net.set_precision(mode)
     x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
     with torch.no_grad():
         eps = net((x0, 4.0 * torch.ones(2, 1, device=dev)))
@@ -461,7 +463,7 @@ def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
         sk0 = torch.from_numpy(synth.uniform(f"sws/{L}/{layer}", (B, C_, L), 1, -1.0, 1.0)).to(dev)
         pt = torch.from_numpy(synth.uniform(f"swp/{layer}", (C_,), 1, -0.5, 0.5)).to(dev)
         outs = {}
-        for mode in ("f32", "f32s", "bf16"):
+        for mode in ("f32", "f32s", "f32h", "bf16"):
             net.set_precision(mode)
             eng = net.engine()
             sk, ho = sk0.clone(), torch.empty_like(h)
@@ -470,6 +472,7 @@ def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
             outs[mode] = (ho.cpu().numpy(), sk.cpu().numpy())
         for k in (0, 1):
             assert rel_err(outs["f32s"][k], outs["f32"][k]) < 2e-6, (B, L, layer, k)
+            assert rel_err(outs["f32h"][k], outs["f32"][k]) < 2e-6, (B, L, layer, k)
             assert rel_err(outs["bf16"][k], outs["f32"][k]) < 3e-2, (B, L, layer, k)
 
 
