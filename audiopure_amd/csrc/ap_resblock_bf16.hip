@@ -358,6 +358,41 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   }
   mark(4);
 
+  // GEMM2's first requests go out BEFORE the gate and before anything with HBM latency or bulk: the CU's memory pipe
+  // serves requests in order and vmcnt retires in order, so a bias vector or weight fragment requested after the
+  // read-modify-write operands (or after the previous pass's 16 stores per wave) would hold the first MFMA until all
+  // of those have gone through.  pass 0's k-loop prefetches straight into pass 1's fragments (adjacent in the packed
+  // image) and pass 1's bias is fetched before pass 0's epilogue.
+  constexpr int NKS = C / 16;
+  static_assert(NKS % 8 == 0, "GEMM2 k-steps processed in pairs of 4-step sets");
+  const float *b2l = b2, *ptl = pt;
+  asm volatile("" : "+s"(b2l), "+s"(ptl));
+  const u32x4 *ap2 = reinterpret_cast<const u32x4 *>(w2p) + (size_t)(wave * 2) * NKS * 64 + lane;   // pass 0, then pass 1
+  bf16x8 p0[4], p1[4];
+  auto load_a4 = [&](bf16x8(&a)[4], int gks) {                   // gks = k-step over both passes, clamped to the last set
+    const u32x4 *base = ap2 + (size_t)(gks <= 2 * NKS - 4 ? gks : 2 * NKS - 4) * 64;
+#pragma unroll
+    for (int s = 0; s < 4; s++) a[s] = __builtin_bit_cast(bf16x8, base[s * 64]);
+  };
+  float4 bias[4];
+  auto fetch_bias = [&](auto pass_tag) {
+    constexpr int pass = decltype(pass_tag)::value;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c = 32 * wave + 8 * q + 4 * hh;
+      float4 v = *reinterpret_cast<const float4 *>(b2l + pass * C + c);
+      if (pass == 0) {                                           // u = h + part_t re-enters the residual
+        const float4 pv = *reinterpret_cast<const float4 *>(ptl + c);
+        v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+      }
+      bias[q] = v;
+    }
+  };
+  fetch_bias(std::integral_constant<int, 0>{});
+  load_a4(p0, 0);
+  load_a4(p1, 4);
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- gate (WaveNet.py:90) -> g image [col][channel] bf16
 #pragma unroll
   for (int ct = 0; ct < 4; ct++) {
@@ -379,8 +414,6 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   // beside them): pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip.  (WaveNet.py:93-97, :133)
   // Those values (h for the residual, the running skip) are fetched before the pass's GEMM and consumed after it: no
   // exposed latency, and no float atomics (their ~1.3 TB/s chip-wide rate would cap the launch).
-  constexpr int NKS = C / 16;
-  static_assert(NKS % 8 == 0, "GEMM2 k-steps processed in pairs of 4-step sets");
   const unsigned char *gb = lds + GOFF + (j * GSTRIDE + 8 * hh) * 2;
   const float RS = 0.707106781186547524f;
   const __amdgpu_buffer_rsrc_t srs = clip_rsrc(skip);
@@ -398,8 +431,6 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     }
   }                                                             // 0x80000000: out of the clip's range -> load 0 / store dropped
   float *patch = reinterpret_cast<float *>(lds + GBYTES) + wave * 32 * PSTR;
-  const float *b2l = b2, *ptl = pt;
-  asm volatile("" : "+s"(b2l), "+s"(ptl));
   auto gemm2_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
     float pre[4][16];
@@ -425,12 +456,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     f32x16 ac[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int c = 32 * wave + 8 * q + 4 * hh;
-      float4 v = *reinterpret_cast<const float4 *>(b2l + pass * C + c);
-      if (pass == 0) {                                           // u = h + part_t re-enters the residual
-        const float4 pv = *reinterpret_cast<const float4 *>(ptl + c);
-        v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
-      }
+      const float4 v = bias[q];
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) {
         ac[ct][4 * q + 0] = v.x;
@@ -439,12 +465,6 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
         ac[ct][4 * q + 3] = v.w;
       }
     }
-    const u32x4 *ap2 = reinterpret_cast<const u32x4 *>(w2p) + (size_t)(wave * 2 + pass) * NKS * 64 + lane;
-    bf16x8 p0[4], p1[4];
-    auto load_a4 = [&](bf16x8(&a)[4], const u32x4 *base) {
-#pragma unroll
-      for (int s = 0; s < 4; s++) a[s] = __builtin_bit_cast(bf16x8, base[s * 64]);
-    };
     auto mma4b = [&](const bf16x8(&a)[4], const unsigned char *xb) {
 #pragma unroll
       for (int s = 0; s < 4; s++) {
@@ -457,19 +477,22 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
           ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv[ct], ac[ct], 0, 0, 0);
       }
     };
-    load_a4(p0, ap2);
 #pragma unroll 1
     for (int ks = 0; ks < NKS; ks += 8) {
-      load_a4(p1, ap2 + (size_t)(ks + 4) * 64);
-      __builtin_amdgcn_sched_barrier(0);
       mma4b(p0, gb + ks * 32);
       __builtin_amdgcn_sched_barrier(0);
-      load_a4(p0, ap2 + (size_t)(ks + 8 < NKS ? ks + 8 : ks) * 64);
+      load_a4(p0, pass * NKS + ks + 8);
       __builtin_amdgcn_sched_barrier(0);
       mma4b(p1, gb + (ks + 4) * 32);
       __builtin_amdgcn_sched_barrier(0);
+      load_a4(p1, pass * NKS + ks + 12);
+      __builtin_amdgcn_sched_barrier(0);
     }
     mark(6 + 2 * pass);
+    if (pass == 0) {
+      fetch_bias(std::integral_constant<int, 1>{});              // ahead of this pass's stores
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const bool add = (pass == 0) || accumulate;
     const float scale = pass == 0 ? RS : 1.0f;
     if (!(ablate & 1)) {
