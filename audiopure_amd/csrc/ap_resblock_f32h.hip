@@ -96,7 +96,7 @@ __global__ void pack_w1_splith_kernel(const float *__restrict__ w1f, _Float16 *_
   int c = ch * BKC + 8 * hh + jj;
   int o = rt * C + 32 * w + i;
   _Float16 p[2];
-  split2(w1f[((size_t)o * C + c) * 3 + ks] * WSC, p);
+  split2(fminf(fmaxf(w1f[((size_t)o * C + c) * 3 + ks] * WSC, -60000.0f), 60000.0f), p);   // |w| < 3750, like the activations
   size_t frag = ((((size_t)w * NCH + ch) * 3 + ks) * 2 + rt) * 2;
 #pragma unroll
   for (int s = 0; s < 2; s++) out[((frag + s) * 64 + lane) * 8 + jj] = p[s];
@@ -118,7 +118,7 @@ __global__ void pack_w2_splith_kernel(const float *__restrict__ w2f, _Float16 *_
   int k = ks * 16 + 8 * hh + jj;
   int o = pass * C + 32 * w + i;
   _Float16 p[2];
-  split2(w2f[(size_t)o * C + k] * WSC, p);
+  split2(fminf(fmaxf(w2f[(size_t)o * C + k] * WSC, -60000.0f), 60000.0f), p);
   size_t frag = (((size_t)w * 2 + pass) * NKS + ks) * 2;
 #pragma unroll
   for (int s = 0; s < 2; s++) out[((frag + s) * 64 + lane) * 8 + jj] = p[s];
