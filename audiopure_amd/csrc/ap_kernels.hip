@@ -287,10 +287,15 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
   for (int rt = 0; rt < 4; rt++) {
     const int obase = (rt & 1) * C + 64 * mw + 32 * (rt >> 1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      float bv = b1[obase + rowoff(r, hh)];
+    for (int q = 0; q < 4; q++) {                                // rows rowoff(4q .. 4q+3, hh) are consecutive
+      const float4 bv = *reinterpret_cast<const float4 *>(b1 + obase + 8 * q + 4 * hh);
 #pragma unroll
-      for (int ct = 0; ct < 2; ct++) acc[rt][ct][r] = bv;
+      for (int ct = 0; ct < 2; ct++) {
+        acc[rt][ct][4 * q + 0] = bv.x;
+        acc[rt][ct][4 * q + 1] = bv.y;
+        acc[rt][ct][4 * q + 2] = bv.z;
+        acc[rt][ct][4 * q + 3] = bv.w;
+      }
     }
   }
 
@@ -366,8 +371,10 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
     int ch = 0, g = 0;
 #pragma unroll 1
     for (int Gi = 0; Gi < G::NG1; Gi += 2) {
-      if (g == 0 && ch + 1 < G::NCHUNK && !(ablate & 8)) issue_loads(ch + 1);
+      // vmcnt retires in issue order: the next weight group is requested BEFORE the (HBM-latency) X loads of the next
+      // chunk, so its wait does not include them
       load_a(a1, ap, Gi + 1);
+      if (g == 0 && ch + 1 < G::NCHUNK && !(ablate & 8)) issue_loads(ch + 1);
       __builtin_amdgcn_sched_barrier(0);
       const float *xb = lds + (ch & 1) * G::XBUF + (g * 8 + hh) * TT + colbase;
       mma4(a0, xb);
@@ -410,14 +417,26 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
     for (int rt = 0; rt < 4; rt++) {
       const int cb = 64 * mw + 32 * (rt & 1);
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int c = cb + rowoff(r, hh);
-        float bv = (rt < 2) ? b2l[c] + ptl[c] : b2l[C + c];
+      for (int q = 0; q < 4; q++) {                              // rows rowoff(4q .. 4q+3, hh) are consecutive: one 16-B load
+        const int c = cb + 8 * q + 4 * hh;
+        float4 bv = *reinterpret_cast<const float4 *>(b2l + (rt < 2 ? 0 : C) + c);
+        if (rt < 2) {
+          const float4 pv = *reinterpret_cast<const float4 *>(ptl + c);
+          bv.x += pv.x; bv.y += pv.y; bv.z += pv.z; bv.w += pv.w;
+        }
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) acc[rt][ct][r] = bv;
+        for (int ct = 0; ct < 2; ct++) {
+          acc[rt][ct][4 * q + 0] = bv.x;
+          acc[rt][ct][4 * q + 1] = bv.y;
+          acc[rt][ct][4 * q + 2] = bv.z;
+          acc[rt][ct][4 * q + 3] = bv.w;
+        }
       }
     }
   }
+  const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)mw * G::NG2 * 4 * 64 + lane;
+  load_a(a0, ap2, 0);                                            // ahead of the residual-input loads below (in-order vmcnt)
+  load_a(a1, ap2, 1);
   __syncthreads();
 
   // The residual input h[c][t] of this wave's 64 x 64 patch is fetched now (64 VGPRs) and consumed after GEMM2,
@@ -442,20 +461,18 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
               float, __builtin_amdgcn_raw_buffer_load_b32(hrs, evoff[rt][ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
   }
 
-  const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(w2p) + (size_t)mw * G::NG2 * 4 * 64 + lane;
-  load_a(a0, ap2, 0);
   {
     static_assert(G::NG2 % 2 == 0, "pair-unrolled loop");
 #pragma unroll 1
     for (int Gi = 0; Gi < G::NG2; Gi += 2) {
-      load_a(a1, ap2, Gi + 1);
-      __builtin_amdgcn_sched_barrier(0);
       const float *gb = lds + (Gi * 8 + hh) * TT + colbase;
       mma4(a0, gb);
       __builtin_amdgcn_sched_barrier(0);
       load_a(a0, ap2, (Gi + 2 < G::NG2) ? Gi + 2 : Gi);
       __builtin_amdgcn_sched_barrier(0);
       mma4(a1, gb + 8 * TT);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(a1, ap2, (Gi + 3 < G::NG2) ? Gi + 3 : Gi + 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
