@@ -353,8 +353,9 @@ class NativeConvNet(nn.Module):
 
     def set_precision(self, mode: str):
         """"f32": fp32 MFMA (default).  "f32s": eligible conv layers on the bf16 MFMA with exactly 3-way-split fp32
-        operands (AP_CONV_SPLIT) -- fp32-class results, faster."""
-        self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100}[mode]
+        operands (AP_CONV_SPLIT) -- fp32-class results, faster.  "f32h": the same layers with operands as two fp16 parts
+        on the fp16 MFMA (AP_CONV_SPLIT_F16; weights and activations below 3750 in magnitude) -- faster again."""
+        self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100, "f32h": 0x400}[mode]
         return self
 
     def _get_name(self):                       # the scripts print / branch on the classifier's class name

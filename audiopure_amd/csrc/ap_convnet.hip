@@ -354,6 +354,13 @@ typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
 typedef float cf32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ch16x2 __attribute__((ext_vector_type(2)));
+// AP_CONV_SPLIT_F16 (flags bit 10): the arithmetic of ap_resblock_f32h.hip -- operands as two fp16 parts (22 significant
+// bits), three partial products on v_mfma_f32_32x32x16_f16, weights x 2^4 at pack time and activations x 2^4 at staging
+// (exact; the epilogue multiplies by 2^-8), scaled values clamped to +-60000.
+constexpr float CWSC = 16.0f, CXSC = 16.0f;
+
 __device__ __forceinline__ void csplit3(float x, __bf16 (&p)[3]) {
   p[0] = (__bf16)x;
   const float r1 = x - (float)p[0];
@@ -361,12 +368,13 @@ __device__ __forceinline__ void csplit3(float x, __bf16 (&p)[3]) {
   p[2] = (__bf16)(r1 - (float)p[1]);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const __bf16 *__restrict__ afrag) {
+template <int BM, int BN, bool H16 = false>
+__global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const void *__restrict__ afrag) {
   constexpr int BK = 16, NX = BM / 64, NY = BN / 64, RS = 48;   // RS: bytes per column row of a B image
   constexpr int IMG = BN * RS;
+  constexpr int NS = H16 ? 2 : 3;                               // parts per operand
   static_assert(BN == 128, "staging map: 256 threads = 128 columns x 2 k' octets");
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][3][IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][NS][IMG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int j = lane & 31, hh = lane >> 5;
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
 #pragma unroll
   for (int x_ = 0; x_ < NX; x_++) {
     const int mt = min((m0 >> 5) + NX * wm + x_, MT - 1);
-    af[x_] = reinterpret_cast<const cu32x4 *>(afrag) + ((size_t)g * MT + mt) * KS * 3 * 64 + lane;
+    af[x_] = reinterpret_cast<const cu32x4 *>(afrag) + ((size_t)g * MT + mt) * KS * NS * 64 + lane;
   }
   const int nchunk = KK * CPT;
   float br[8];
@@ -401,29 +409,38 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
       br[i] = ok ? v : 0.f;
     }
   };
-  auto load_a = [&](cbf16x8(&aa)[NX][3], int c) {
+  auto load_a = [&](cu32x4(&aa)[NX][NS], int c) {
 #pragma unroll
     for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
-      for (int sp = 0; sp < 3; sp++) aa[x_][sp] = __builtin_bit_cast(cbf16x8, af[x_][(size_t)(3 * c + sp) * 64]);
+      for (int sp = 0; sp < NS; sp++) aa[x_][sp] = af[x_][(size_t)(NS * c + sp) * 64];
   };
   auto store_b = [&](int buf) {
-    cu32x4 pk[3];
+    cu32x4 pk[NS];
 #pragma unroll
     for (int pr = 0; pr < 4; pr++) {
       float v0 = br[2 * pr], v1 = br[2 * pr + 1];
+      if constexpr (H16) {
+        const cf32x2 v = {__builtin_amdgcn_fmed3f(v0 * CXSC, -60000.0f, 60000.0f),
+                          __builtin_amdgcn_fmed3f(v1 * CXSC, -60000.0f, 60000.0f)};
+        const ch16x2 hi = __builtin_convertvector(v, ch16x2);
+        const ch16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, cf32x2), ch16x2);
+        pk[0][pr] = __builtin_bit_cast(unsigned, hi);
+        pk[1][pr] = __builtin_bit_cast(unsigned, lo);
+      } else {
 #pragma unroll
-      for (int sp = 0; sp < 3; sp++) {
-        const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v0, v1}, cbf16x2));
-        pk[sp][pr] = w;
-        if (sp < 2) {
-          v0 -= __builtin_bit_cast(float, w << 16);
-          v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+        for (int sp = 0; sp < 3; sp++) {
+          const unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(cf32x2{v0, v1}, cbf16x2));
+          pk[sp][pr] = w;
+          if (sp < 2) {
+            v0 -= __builtin_bit_cast(float, w << 16);
+            v1 -= __builtin_bit_cast(float, w & 0xffff0000u);
+          }
         }
       }
     }
 #pragma unroll
-    for (int sp = 0; sp < 3; sp++) *reinterpret_cast<cu32x4 *>(&Bs[buf][sp][nl * RS + ko * 16]) = pk[sp];
+    for (int sp = 0; sp < NS; sp++) *reinterpret_cast<cu32x4 *>(&Bs[buf][sp][nl * RS + ko * 16]) = pk[sp];
   };
   f32x16 acc[NX][NY];
 #pragma unroll
@@ -432,22 +449,32 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
     for (int y_ = 0; y_ < NY; y_++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[x_][y_][r] = 0.f;
-  auto compute = [&](const cbf16x8(&aa)[NX][3], int buf) {
+  auto compute = [&](const cu32x4(&aa)[NX][NS], int buf) {
 #pragma unroll
     for (int y_ = 0; y_ < NY; y_++) {
-      cbf16x8 bv[3];
+      cu32x4 bv[NS];
 #pragma unroll
-      for (int sp = 0; sp < 3; sp++)
-        bv[sp] = *reinterpret_cast<const cbf16x8 *>(&Bs[buf][sp][(32 * NY * wn + 32 * y_ + j) * RS + hh * 16]);
+      for (int sp = 0; sp < NS; sp++)
+        bv[sp] = *reinterpret_cast<const cu32x4 *>(&Bs[buf][sp][(32 * NY * wn + 32 * y_ + j) * RS + hh * 16]);
 #pragma unroll
       for (int x_ = 0; x_ < NX; x_++) {
-#define AP_CT(i, jx) acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[x_][i], bv[jx], acc[x_][y_], 0, 0, 0);
-        AP_CT(0, 0) AP_CT(0, 1) AP_CT(1, 0) AP_CT(0, 2) AP_CT(2, 0) AP_CT(1, 1)
+        if constexpr (H16) {
+#define AP_CT(i, jx)                                                                                                    \
+  acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ch16x8, aa[x_][i]), __builtin_bit_cast(ch16x8, bv[jx]), \
+                                                       acc[x_][y_], 0, 0, 0);
+          AP_CT(0, 0) AP_CT(0, 1) AP_CT(1, 0)
 #undef AP_CT
+        } else {
+#define AP_CT(i, jx)                                                                                                       \
+  acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, aa[x_][i]), __builtin_bit_cast(cbf16x8, bv[jx]), \
+                                                        acc[x_][y_], 0, 0, 0);
+          AP_CT(0, 0) AP_CT(0, 1) AP_CT(1, 0) AP_CT(0, 2) AP_CT(2, 0) AP_CT(1, 1)
+#undef AP_CT
+        }
       }
     }
   };
-  cbf16x8 a0[NX][3], a1[NX][3];
+  cu32x4 a0[NX][NS], a1[NX][NS];
   load_a(a0, 0);
   load_b(0);
   store_b(0);
@@ -462,7 +489,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
 #pragma unroll
     for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
-      for (int sp = 0; sp < 3; sp++) a0[x_][sp] = a1[x_][sp];
+      for (int sp = 0; sp < NS; sp++) a0[x_][sp] = a1[x_][sp];
     __syncthreads();
   }
 #pragma unroll
@@ -479,6 +506,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_split_kernel(ConvArgs a, const 
             const int co = g * Mg + m;
             const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
             float v = acc[x_][y_][r];
+            if constexpr (H16) v *= 1.0f / (CWSC * CXSC);
             if (a.bias) v += a.bias[co];
             if (a.res) v += a.res[off];
             if (a.relu) v = fmaxf(v, 0.f);
@@ -515,6 +543,34 @@ __global__ void conv_pack_split_kernel(const float *__restrict__ w, const float 
   const size_t frag = (((size_t)g * MT + mt) * KS + q) * 3;
 #pragma unroll
   for (int sp = 0; sp < 3; sp++) out[((frag + sp) * 64 + lane) * 8 + jj] = p[sp];
+}
+
+// w x 2^4 -> two fp16 parts as A fragments of v_mfma_f32_32x32x16_f16: [group][row tile][k'/16][split][lane][8]
+__global__ void conv_pack_splith_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                        _Float16 *__restrict__ out, int Cout, int Cg, int KK, int groups) {
+  const int Mg = Cout / groups, MT = (Mg + 31) / 32, Kg = Cg * KK, KS = Kg / 16;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)groups * MT * KS * 64 * 8;
+  if (idx >= total) return;
+  const int jj = idx & 7, lane = (idx >> 3) & 63;
+  size_t rest = idx >> 9;
+  const int q = rest % KS; rest /= KS;
+  const int mt = rest % MT, g = rest / MT;
+  const int i = lane & 31, h = lane >> 5;
+  const int kp = 16 * q + 8 * h + jj;
+  const int r = kp / Cg, ci = kp - r * Cg;
+  const int m = 32 * mt + i;
+  float v = 0.f;
+  if (m < Mg) {
+    const int co = g * Mg + m;
+    v = w[((size_t)co * Cg + ci) * KK + r];
+    if (scale) v *= scale[co];
+  }
+  v = fminf(fmaxf(v * CWSC, -60000.0f), 60000.0f);
+  const _Float16 p0 = (_Float16)v, p1 = (_Float16)(v - (float)p0);
+  const size_t frag = (((size_t)g * MT + mt) * KS + q) * 2;
+  out[((frag + 0) * 64 + lane) * 8 + jj] = p0;
+  out[((frag + 1) * 64 + lane) * 8 + jj] = p1;
 }
 
 // w [Cout][Cin/g][kh][kw] (* scale) -> A-operand fragments of v_mfma_f32_32x32x2_f32 in tap-major K order:
@@ -645,11 +701,17 @@ static size_t conv_split_floats(int Cout, int Cin_g, int kh, int kw, int groups)
   return (conv_frag_elems(Cout, Cin_g, kh, kw, groups) * 3 / 2 + 3) & ~(size_t)3;
 }
 
+// fourth image (2 x fp16 per weight = 1 float)
+static size_t conv_splith_floats(int Cout, int Cin_g, int kh, int kw, int groups) {
+  return (conv_frag_elems(Cout, Cin_g, kh, kw, groups) + 3) & ~(size_t)3;
+}
+
 extern "C" size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups) {
   if (Cout < 1 || Cin_g < 1 || kh < 1 || kw < 1 || groups < 1 || Cout % groups) return 0;
   size_t n = (size_t)Cout * Cin_g * kh * kw;
   if (conv_has_frag(Cout, Cin_g, groups))
-    n = ((n + 3) & ~(size_t)3) + conv_frag_elems(Cout, Cin_g, kh, kw, groups) + conv_split_floats(Cout, Cin_g, kh, kw, groups);
+    n = ((n + 3) & ~(size_t)3) + conv_frag_elems(Cout, Cin_g, kh, kw, groups) + conv_split_floats(Cout, Cin_g, kh, kw, groups) +
+        conv_splith_floats(Cout, Cin_g, kh, kw, groups);
   return n;
 }
 
@@ -665,6 +727,9 @@ extern "C" int ap_conv2d_pack(const float *w, const float *scale, float *wT, int
                                                                                        kh * kw, groups);
     conv_pack_split_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         w, scale, reinterpret_cast<__bf16 *>(wT + n4 + nf), Cout, Cin_g, kh * kw, groups);
+    conv_pack_splith_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        w, scale, reinterpret_cast<_Float16 *>(wT + n4 + nf + conv_split_floats(Cout, Cin_g, kh, kw, groups)), Cout, Cin_g,
+        kh * kw, groups);
   }
   AP_HIP(hipGetLastError());
   return 0;
@@ -681,9 +746,9 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   ConvArgs a;
   a.x = x; a.wT = wT; a.bias = bias; a.res = res; a.out = out;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
-  // flags: bit 0 ReLU, bit 8 AP_CONV_SPLIT, bit 9 AP_CONV_1D (padding and dilation apply to W only: Conv1d over
+  // flags: bit 0 ReLU, bit 8 AP_CONV_SPLIT, bit 10 AP_CONV_SPLIT_F16, bit 9 AP_CONV_1D (padding and dilation apply to W only: Conv1d over
   // [B][C][1][L]), bits 16-31 dilation (0 = 1)
-  const bool split = (relu >> 8) & 1, one_d = (relu >> 9) & 1;
+  const bool split = (relu >> 8) & 1, one_d = (relu >> 9) & 1, splith = (relu >> 10) & 1;
   const int dil = (relu >> 16) ? (relu >> 16) : 1;
   relu &= 1;
   a.groups = groups; a.relu = relu; a.x_cstride = x_cstride; a.x_coff = x_coff;
@@ -701,7 +766,17 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
     const size_t n1 = (size_t)Cout * (Cin / groups) * kh * kw;
     const float *afrag = wT + ((n1 + 3) & ~(size_t)3);
-    if (split) {                                                // fp32 results on the bf16 pipe (3-way split operands)
+    if (splith) {                                               // two fp16 parts per operand, three partial products
+      const void *hfrag = afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups) +
+                          conv_split_floats(Cout, Cin / groups, kh, kw, groups);
+      if (Mg < 128) {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
+        conv2d_split_kernel<64, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, hfrag);
+      } else {
+        dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+        conv2d_split_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, hfrag);
+      }
+    } else if (split) {                                         // fp32 results on the bf16 pipe (3-way split operands)
       const __bf16 *sfrag = reinterpret_cast<const __bf16 *>(afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups));
       if (Mg < 128) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);

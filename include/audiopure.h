@@ -33,6 +33,7 @@
 
 #define AP_CONV_SPLIT 0x100
 #define AP_CONV_1D 0x200
+#define AP_CONV_SPLIT_F16 0x400
 #define AP_CONV_DILATION(d) ((d) << 16)
 
 #ifdef __cplusplus
@@ -234,7 +235,9 @@ int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L
  *   zero padding); bias / res may be NULL; res has the shape of out.  conv-as-GEMM on v_mfma_f32_32x32x2_f32.
  *   `relu` is a flag word: bit 0 = fused ReLU, bit 8 (AP_CONV_SPLIT) = run eligible layers (Cin/g % 16 == 0,
  *   Cout/g >= 64) on the bf16 MFMA with exactly 3-way-split fp32 operands (AP_PREC_F32_SPLIT's arithmetic); bit 9
- *   (AP_CONV_1D) = padding and dilation apply to W only (nn.Conv1d over [B][C][1][L]); bits 16-31 = dilation (0 = 1).
+ *   (AP_CONV_1D) = padding and dilation apply to W only (nn.Conv1d over [B][C][1][L]); bit 10 (AP_CONV_SPLIT_F16) = the
+ *   same layers with operands as two fp16 parts, three partial products on the fp16 MFMA (AP_PREC_F32_SPLIT_F16's
+ *   arithmetic: |w|, |x| < 3750); bits 16-31 = dilation (0 = 1).
  *   nn.Linear is the kh = kw = H = W = 1 case. */
 size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups);   /* floats ap_conv2d_pack writes */
 int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw, int groups,

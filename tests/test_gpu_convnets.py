@@ -54,10 +54,11 @@ def test_family_structures_match_module(dev):
     assert rel_err(NativeConvNet(m).eval()(x.to(dev)).cpu().numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("flags", [0, 0x100])
+@pytest.mark.parametrize("flags", [0, 0x100, 0x400])
 def test_conv2d_primitive_edge_shapes(dev, flags):
     """ap_conv2d_fwd alone: grouped, strided, 1x1, Cout not a multiple of the tile, N not a multiple of the tile; with
-    flags = AP_CONV_SPLIT the eligible layers run on the bf16 MFMA with 3-way-split operands -- same tolerance."""
+    flags = AP_CONV_SPLIT / AP_CONV_SPLIT_F16 the eligible layers run on the bf16 / fp16 MFMA with split operands -- same
+    tolerance."""
     import torch.nn.functional as F
     from audiopure_amd import _native as N
     lib = N.lib()

@@ -147,7 +147,7 @@ def _unet_vjp_case(dev, model_cpu, t, mode="f32", tol=2e-4):
     assert err < tol, (t, mode, err)
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32s"])
+@pytest.mark.parametrize("mode", ["f32", "f32s", "f32h"])
 def test_mini_unet_input_gradient_matches_autograd_of_the_oracle(dev, mode):
     for t in (0, 37, 999):
         _unet_vjp_case(dev, mini_unet(), t, mode)

@@ -10,7 +10,7 @@ from audiopure_amd.diffusion_models.improved_diffusion_sde import RevImprovedDif
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mode = "f32"
-if len(sys.argv) > 2 and sys.argv[2] in ("f32", "f32s"):   # arithmetic of the conv layers
+if len(sys.argv) > 2 and sys.argv[2] in ("f32", "f32s", "f32h"):   # arithmetic of the conv layers
     mode = sys.argv[2]
 elif len(sys.argv) > 2:                                # A/B switch of the conv dispatch (ap_debug_conv_path)
     from audiopure_amd import _native as N
