@@ -55,6 +55,29 @@ def test_eps_vjp_matches_oracle_autograd(dev, C_, NL, L, step):
     assert rel_err(g.cpu().numpy(), g_ref.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["f32s", "f32h"])
+def test_eps_vjp_in_the_split_modes_matches_oracle_autograd(dev, mode):
+    """The same check with the network in a split-operand mode (fused block forward in that mode, the backward GEMMs on
+    ap_conv2d_fwd with the matching AP_CONV_SPLIT / AP_CONV_SPLIT_F16 flag): same tolerances as fp32."""
+    from oracle import diffwave_oracle as O
+    from audiopure_amd.diffusion_models._grad import EpsGrad
+    cfg = synth.mini_wavenet_config(256, 4, 12)
+    net, sd = _net(cfg, dev, seed=6)
+    net.set_precision(mode)
+    w = O.fold_state_dict(sd)
+    B, L, step = 2, 900, 9.0
+    x = torch.from_numpy(synth.waveforms(B, L, seed=12))
+    v = torch.from_numpy(synth.uniform(f"vs{L}", (B, 1, L), 1, -1.0, 1.0))
+    xr = x.clone().requires_grad_(True)
+    eps_ref = O.eps_net(w, cfg, xr, torch.full((B, 1), step))
+    (g_ref,) = torch.autograd.grad(eps_ref, xr, v)
+    eg = EpsGrad(net)
+    eps, saved = eg.forward_save(x.to(dev), step)
+    assert rel_err(eps.cpu().numpy(), eps_ref.detach().numpy()) < 2e-5
+    g = eg.backward(saved, v.to(dev))
+    assert rel_err(g.cpu().numpy(), g_ref.numpy()) < 1e-4
+
+
 def test_white_box_gradient_through_rev_diffwave_matches_oracle(dev):
     """loss(classifier-free surrogate: sum of w * purified) differentiated w.r.t. the audio through RevDiffWave's Euler
     chain (t* = 3), as white_box_attack.py:392,437-439 does; reference = autograd through the oracle's SDE chain."""
