@@ -147,6 +147,35 @@ def test_mini_ddpm_chain_matches_reference_golden(golden, mini, dh, dev):
     assert rel_err(x.cpu().numpy(), golden["mini/ddpm_n3"]) < TOL_CHAIN
 
 
+@pytest.mark.parametrize("mode", ["f32", "f32h", "bf16"])
+def test_full_size_batch_is_the_small_batch_on_shared_clips(golden, dev, dh, mode):
+    """BASELINE configs[1] at its full size (512 clips, shipped config, DDPM n = 5): utterances are independent and the
+    Philox noise is keyed on the global utterance index, so clips 0-1 and 510-511 of the 512-clip run must equal, bit
+    for bit, the same clips purified in batches of two; and in fp32 mode with the golden noise tensors the first two
+    clips must meet the reference's golden vectors."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, _ = _net(cfg, dev)
+    net.set_precision(mode)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=5)
+    B = 512
+    x = torch.from_numpy(synth.waveforms(B, 16000, seed=77)).to(dev)
+    x[:2] = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
+    dw.set_noise_source(("philox", 31, 0))
+    big = dw(x)
+    assert big.shape == x.shape and torch.isfinite(big).all()
+    dw.set_noise_source(("philox", 31, 0))
+    assert torch.equal(dw(x[:2]), big[:2])
+    dw.set_noise_source(("philox", 31, 510))
+    assert torch.equal(dw(x[510:]), big[510:])
+    if mode == "f32":
+        z = [torch.from_numpy(np.concatenate([synth.noise(d, 2, 16000, seed=1234), synth.noise(d, 2, 16000, seed=9)]))
+             for d in range(5)]
+        dw.set_noise_source(z)
+        xp = dw(x[:4])
+        assert rel_err(xp[:2].cpu().numpy(), golden["full/ddpm_n5/x"]) < TOL_CHAIN
+
+
 def test_full_eps_matches_reference_golden(golden, full, dev):
     cfg, net, _ = full
     x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
