@@ -1,0 +1,50 @@
+"""Randomised hazard hunt over the four residual-block kernels: python tools/fuzz_blocks.py [cases] [seed]
+Random batch / length (multiples of 4 and not) / layer (dilation) / accumulate flag; every mode is run twice (bit-identical
+results required) and compared with the exact fp32 kernel (split modes 5e-6 of max, bf16 3e-2)."""
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audiopure_amd import synth, _native as N
+from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+cfg = synth.mini_wavenet_config(256, 12, 12)
+nets = {}
+for mode in ("f32", "f32s", "f32h", "bf16"):
+    net = WaveNet_Speech_Commands(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(cfg, 3).items()})
+    nets[mode] = net.to(dev).set_precision(mode)
+tol = {"f32s": 5e-6, "f32h": 5e-6, "bf16": 3e-2}      # rounding-noise level at input amplitudes up to 3; a hazard shows as 1e-2 .. 1
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+worst = {k: 0.0 for k in tol}
+bad = 0
+for i in range(cases):
+    B = int(rng.integers(1, 7))
+    L = int(rng.choice([rng.integers(1, 260), rng.integers(260, 5000), 4 * rng.integers(32, 4100), 16000]))
+    layer = int(rng.integers(0, 12))
+    acc = int(rng.integers(0, 2))
+    h = torch.randn(B, 256, L, device=dev) * float(rng.choice([0.3, 1.0, 3.0]))
+    sk0 = torch.randn(B, 256, L, device=dev)
+    pt = torch.randn(256, device=dev) * 0.5
+    res = {}
+    for mode, net in nets.items():
+        eng = net.engine()
+        outs = []
+        for rep in range(2):
+            ho, sk = torch.full_like(h, float("nan")), sk0.clone()
+            N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho), N.ptr(sk), acc, B, L, N.stream()))
+            outs.append((ho, sk))
+        if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+            if not (mode == "f32" and acc):          # the fp32 kernel accumulates skip with float atomics: order-dependent bits
+                print(f"NONDETERMINISTIC {mode} B={B} L={L} layer={layer} acc={acc}"); bad += 1
+        if not (torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()):
+            print(f"NONFINITE {mode} B={B} L={L} layer={layer} acc={acc}"); bad += 1
+        res[mode] = outs[0]
+    for mode, t in tol.items():
+        e = max(rel(res[mode][0], res["f32"][0]), rel(res[mode][1], res["f32"][1]))
+        worst[mode] = max(worst[mode], e)
+        if e > t:
+            print(f"MISMATCH {mode} {e:.3e} B={B} L={L} layer={layer} acc={acc}"); bad += 1
+print(f"{cases} cases, {bad} failures; worst vs fp32 kernel: " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+sys.exit(1 if bad else 0)
