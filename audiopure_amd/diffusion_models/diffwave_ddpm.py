@@ -225,3 +225,33 @@ def create_diffwave_model(model_path, config_path, reverse_timestep=25, device=N
     net.load_state_dict(checkpoint["model_state_dict"])
     net = net.to(device)
     return DiffWave(model=net, diffusion_hyperparams=diffusion_hyperparams, reverse_timestep=reverse_timestep)
+
+
+class ReffWave(DiffWave):
+    """``ReffWave`` (diffwave_ddpm.py:251-348; not used by any script, kept for the module's surface): ``num_re`` rounds of
+    diffuse-to-t* + one-shot denoise.  One round is a single native chain call (the q-sample plus one link)."""
+
+    def __init__(self, model: WaveNet_Speech_Commands, diffusion_hyperparams: dict, reverse_timestep: int = 200,
+                 num_re: int = 5):
+        super().__init__(model=model, diffusion_hyperparams=diffusion_hyperparams, reverse_timestep=reverse_timestep)
+        self.num_re = num_re
+
+    def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
+        x = self._prep(waveforms)
+        t = int(self.reverse_timestep) - 1                                   # :280-283,:306-313
+        ab = float(self.diffusion_hyperparams["Alpha_bar"][t].double())
+        link = [(float(t), math.sqrt(1.0 / ab), -math.sqrt(1.0 / ab - 1.0), 0.0, 0)]
+        src = self._noise
+        try:
+            for i in range(self.num_re):                                     # :276-278
+                if isinstance(src, tuple):                                   # counter-based stream: a fresh key per round
+                    self._noise = ("philox", src[1] + i, src[2])
+                x = self._chain(x, link, math.sqrt(ab), math.sqrt(1.0 - ab), n_draws=1)
+        finally:
+            if isinstance(src, tuple):
+                self._noise = src
+        return x
+
+    def diffusion(self, x_0):
+        return self._diffusion(x_0)                                          # :284-304
+

@@ -226,6 +226,31 @@ def test_full_denoise_helpers_match_reference_golden(golden, full, dh, dev):
     assert float(sigma) == float(dh["Sigma"][4])
 
 
+def test_reffwave_rounds_match_oracle_composition(mini, dh, dev):
+    """ReffWave (diffwave_ddpm.py:251-313): num_re rounds of q-sample + one-shot denoise, each round one native chain
+    call, against the same composition of the oracle's q_sample / one_shot_denoise on the same noise tensors."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import ReffWave
+    O = _oracle()
+    cfg, net, sd = mini
+    w = O.fold_state_dict(sd)
+    B, L, t_star, rounds = 2, 2500, 7, 3
+    x0 = torch.from_numpy(synth.waveforms(B, L, seed=21))
+    z = [torch.from_numpy(synth.noise(d, B, L, seed=21)) for d in range(rounds)]
+    ref = x0
+    with torch.no_grad():
+        for i in range(rounds):
+            ref = O.one_shot_denoise(w, cfg, dh, O.q_sample(dh, ref, t_star, z[i]), t_star)
+    rw = ReffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=t_star, num_re=rounds)
+    rw.set_noise_source(list(z))
+    out = rw(x0.to(dev))
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 3 * TOL_EVAL
+    rw.set_noise_source(("philox", 5, 0))                   # counter-based stream: a different key every round
+    a = rw(x0.to(dev))
+    rw.num_re = 1
+    b = rw(x0.to(dev))
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
 def test_sde_matches_oracle_and_reference_drift(golden, mini, dh, dev):
     import types
     from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
