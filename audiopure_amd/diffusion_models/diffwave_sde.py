@@ -47,6 +47,16 @@ class RevVPSDE(torch.nn.Module):
     def _disc(self, t):
         return int(self._scale_timesteps(t.reshape(-1)[:1].cpu())[0]) - 1    # :76
 
+    def vpsde_fn(self, t, x):
+        """Forward VP-SDE drift / diffusion at reference time t (diffwave_sde.py:73-80)."""
+        k = self._disc(t)
+        beta_t = float(self.discrete_betas[k]) * self.N
+        return -0.5 * beta_t * x, torch.full((x.shape[0],), math.sqrt(beta_t), device=x.device)
+
+    def rvpsde_fn(self, t, x, return_type='drift'):
+        """Reverse-SDE drift or diffusion at reference time t (diffwave_sde.py:82-116): f and g without the time flip."""
+        return -self.f(1 - t, x) if return_type == 'drift' else self.g(1 - t, x)[:, 0]
+
     def f(self, t, x):
         """Drift of the reverse SDE in torchsde time (diffwave_sde.py:118-125) — one native eps evaluation."""
         if self.score_type != 'guided_diffusion':

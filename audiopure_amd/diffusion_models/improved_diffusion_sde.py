@@ -35,6 +35,64 @@ def sde_step_table(t_star: int, dt: float = 1e-3, beta_min=0.1, beta_max=20.0, N
     return steps
 
 
+class RevVPSDE(torch.nn.Module):
+    """The reverse VP-SDE object of the spectrogram purifier with the reference's constructor and ``f`` / ``g`` /
+    ``vpsde_fn`` / ``rvpsde_fn`` (improved_diffusion_sde.py:48-137); the score is one native UNet evaluation.
+    ``RevImprovedDiffusion`` itself integrates the same drift / diffusion through its coefficient table
+    (``sde_step_table``) instead of calling back into Python per step."""
+
+    def __init__(self, model, score_type='guided_diffusion', beta_min=0.1, beta_max=20, N=1000, img_shape=(1, 32, 32),
+                 model_kwargs=None):
+        super().__init__()
+        self.model = model
+        self.score_type = score_type
+        self.model_kwargs = model_kwargs
+        self.img_shape = img_shape
+        self.beta_0, self.beta_1, self.N = beta_min, beta_max, N
+        self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)
+        self.alphas = 1. - self.discrete_betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
+        self.sqrt_1m_alphas_cumprod = torch.sqrt(1. - self.alphas_cumprod)
+        self.alphas_cumprod_cont = lambda t: torch.exp(-0.5 * (beta_max - beta_min) * t ** 2 - beta_min * t)
+        self.sqrt_1m_alphas_cumprod_neg_recip_cont = lambda t: -1. / torch.sqrt(1. - self.alphas_cumprod_cont(t))
+        self.noise_type = "diagonal"
+        self.sde_type = "ito"
+
+    def _scale_timesteps(self, t):
+        assert torch.all(t <= 1) and torch.all(t >= 0), f't has to be in [0, 1], but get {t} with shape {t.shape}'
+        return (t.float() * self.N).long()                                   # :80-82
+
+    def vpsde_fn(self, t, x):
+        beta_t = self.beta_0 + t * (self.beta_1 - self.beta_0)               # :84-88
+        return -0.5 * beta_t[:, None] * x, torch.sqrt(beta_t)
+
+    def rvpsde_fn(self, t, x, return_type='drift'):
+        drift, diffusion = self.vpsde_fn(t, x)                               # :90-116
+        if return_type != 'drift':
+            return diffusion
+        assert x.ndim == 2 and np.prod(self.img_shape) == x.shape[1], x.shape
+        if self.score_type != 'guided_diffusion':
+            raise NotImplementedError(f'Unknown score type in RevVPSDE: {self.score_type}!')
+        if self.model_kwargs:
+            raise NotImplementedError("audiopure_amd RevVPSDE: model_kwargs (class conditioning) are not built")
+        eps = self.model(x.view(-1, *self.img_shape), self._scale_timesteps(t)).view(x.shape[0], -1)
+        score = self.sqrt_1m_alphas_cumprod_neg_recip_cont(t.float())[:, None].to(x.device) * eps
+        return drift - diffusion[:, None] ** 2 * score
+
+    def f(self, t, x):
+        t = t.expand(x.shape[0]).to(x.device)                               # :118-126
+        drift = self.rvpsde_fn(1 - t, x, return_type='drift')
+        assert drift.shape == x.shape
+        return -drift
+
+    def g(self, t, x):
+        t = t.expand(x.shape[0]).to(x.device)                               # :128-136
+        diffusion = self.rvpsde_fn(1 - t, x, return_type='diffusion')
+        assert diffusion.shape == (x.shape[0],)
+        return diffusion[:, None].expand(x.shape)
+
+
 class RevImprovedDiffusion(torch.nn.Module):
     def __init__(self, args, config=None, device=None):
         super().__init__()
@@ -46,6 +104,7 @@ class RevImprovedDiffusion(torch.nn.Module):
         model = create_model(**model_and_diffusion_defaults())
         model.load_state_dict(torch.load(args.ddpm_path, map_location="cpu"))
         self.model = model.eval().to(self.device)
+        self.rev_vpsde = RevVPSDE(model=self.model, score_type=getattr(args, "score_type", "guided_diffusion"))   # :157-158
         print(f't: {args.t}, rand_t: {args.rand_t}, t_delta: {args.t_delta}')
         print(f'use_bm: {args.use_bm}')
         self._noise = None
@@ -55,6 +114,7 @@ class RevImprovedDiffusion(torch.nn.Module):
         self = cls.__new__(cls)
         torch.nn.Module.__init__(self)
         self.args, self.config, self.model = args, None, model
+        self.rev_vpsde = RevVPSDE(model=model, score_type=getattr(args, "score_type", "guided_diffusion"))
         self.device = next(model.parameters()).device
         self._noise = None
         return self

@@ -226,6 +226,25 @@ def test_full_denoise_helpers_match_reference_golden(golden, full, dh, dev):
     assert float(sigma) == float(dh["Sigma"][4])
 
 
+def test_rev_vpsde_helper_functions_are_f_and_g_without_the_time_flip(mini, dh, dev):
+    """diffwave_sde.RevVPSDE.vpsde_fn / rvpsde_fn (:73-116) against f / g (:118-134)."""
+    import types
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    cfg, net, _ = mini
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+    args = types.SimpleNamespace(t=3, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1)
+    sde = RevDiffWave.from_model(dw, args).rev_vpsde
+    sde.audio_shape = (1, 1200)
+    x = torch.from_numpy(synth.waveforms(2, 1200, seed=4)).to(dev).reshape(2, -1)
+    t = torch.tensor([0.015])
+    drift, diff = sde.vpsde_fn(t, x)
+    beta = float(sde.discrete_betas[2]) * sde.N                      # _scale_timesteps(0.015) - 1 = 2
+    assert torch.allclose(drift, -0.5 * beta * x) and abs(float(diff[0]) - beta ** 0.5) < 1e-7
+    assert torch.equal(sde.rvpsde_fn(t, x, "drift"), -sde.f(1 - t, x))
+    assert torch.equal(sde.rvpsde_fn(t, x, "diffusion"), sde.g(1 - t, x)[:, 0])
+
+
 def test_reffwave_rounds_match_oracle_composition(mini, dh, dev):
     """ReffWave (diffwave_ddpm.py:251-313): num_re rounds of q-sample + one-shot denoise, each round one native chain
     call, against the same composition of the oracle's q_sample / one_shot_denoise on the same noise tensors."""

@@ -206,3 +206,24 @@ def test_white_box_loss_gradient_end_to_end_with_the_diffspec_defense(dev):
     fd = (lp - lm).item() / (2 * eps)
     an = float((g * d).sum())
     assert abs(fd - an) < 0.15 * abs(an) + 1e-3, (fd, an)
+
+
+def test_spec_rev_vpsde_drift_and_diffusion_match_oracle(dev):
+    """improved_diffusion_sde.RevVPSDE.f / g (torchsde's callbacks, :118-136) with the score from one native UNet
+    evaluation, against the oracle's sde_f_g at a few reference times; RevImprovedDiffusion exposes it as .rev_vpsde."""
+    from oracle import unet_oracle as U
+    from audiopure_amd.diffusion_models.improved_diffusion_sde import RevVPSDE
+    m_cpu = mini_unet()
+    args = types.SimpleNamespace(t=3, rand_t=False, t_delta=0, use_bm=False, sample_step=1, score_type="guided_diffusion")
+    rev = RevImprovedDiffusion.from_model(mini_unet().to(dev), args)
+    sde = rev.rev_vpsde
+    assert isinstance(sde, RevVPSDE) and sde.noise_type == "diagonal" and sde.sde_type == "ito"
+    x = torch.from_numpy(synth.uniform("sdex", (2, 1, 32, 32), 4, -1.0, 1.0))
+    for tau in (0.004, 0.0125, 0.25):
+        f_ref, g_ref = U.sde_f_g(m_cpu, x, torch.tensor(tau, dtype=torch.float32))
+        s = torch.tensor([1.0 - tau], dtype=torch.float32)
+        f = sde.f(s, x.to(dev).reshape(2, -1))
+        g = sde.g(s, x.to(dev).reshape(2, -1))
+        assert f.shape == (2, 1024) and g.shape == (2, 1024)
+        assert rel_err(f.cpu().numpy().reshape(x.shape), f_ref.numpy()) < 1e-4, tau
+        assert abs(float(g[0, 0]) - float(g_ref)) < 1e-6 * max(1.0, float(g_ref))
