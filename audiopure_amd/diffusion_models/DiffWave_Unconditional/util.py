@@ -39,3 +39,21 @@ def calc_diffusion_step_embedding(diffusion_steps, diffusion_step_embed_dim_in):
 
 def std_normal(size, device=None):
     return torch.normal(0, 1, size=size, device=device)
+
+
+def sampling(net, size, diffusion_hyperparams, noise_source=None):
+    """Unconditional generation, the complete reverse process p(x_0 | x_T) (util.py:126-158; inference.py:73): the same
+    chain of links the purifier runs, started from x_T ~ N(0, 1) with all T steps -- one native chain call per
+    workspace-sized batch.  ``noise_source``: as ``DiffWave.set_noise_source`` (draw 0 is x_T)."""
+    from ..diffwave_ddpm import DiffWave
+    _dh = diffusion_hyperparams
+    T = int(_dh["T"])
+    assert len(_dh["Alpha"]) == T and len(_dh["Alpha_bar"]) == T and len(_dh["Sigma"]) == T and len(size) == 3
+    print('begin sampling, total number of reverse steps = %s' % T)
+    dw = DiffWave(model=net, diffusion_hyperparams=_dh, reverse_timestep=T)
+    dw.set_noise_source(noise_source)
+    dev = next(net.parameters()).device
+    zeros = torch.zeros(tuple(size), device=dev)
+    with torch.no_grad():                                   # x_T = 0 * x + 1 * z_0, then the T links
+        return dw._chain(zeros, dw._ddpm_steps(T), 0.0, 1.0, n_draws=T)
+

@@ -245,6 +245,27 @@ def test_rev_vpsde_helper_functions_are_f_and_g_without_the_time_flip(mini, dh, 
     assert torch.equal(sde.rvpsde_fn(t, x, "diffusion"), sde.g(1 - t, x)[:, 0])
 
 
+def test_unconditional_sampling_is_the_full_reverse_chain(mini, dh, dev):
+    """util.sampling (util.py:126-158) with a short schedule: x_T = z_0, then T reverse steps, vs the oracle's
+    ddpm_coefficients loop on the same noise tensors."""
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import sampling, calc_diffusion_hyperparams
+    O = _oracle()
+    cfg, net, sd = mini
+    w = O.fold_state_dict(sd)
+    T, B, L = 6, 2, 1800
+    dh6 = calc_diffusion_hyperparams(T, 1e-4, 0.05)
+    odh = O.diffusion_hyperparams(T, 1e-4, 0.05)
+    z = [torch.from_numpy(synth.noise(d, B, L, seed=33)) for d in range(T)]
+    x = z[0].clone()
+    with torch.no_grad():
+        for i, t in enumerate(range(T - 1, -1, -1)):
+            eps, mu, sigma = O.ddpm_coefficients(w, cfg, odh, x, t)
+            x = mu + sigma * z[1 + i] if t > 0 else mu
+    out = sampling(net, (B, 1, L), dh6, noise_source=list(z))
+    assert out.shape == (B, 1, L)
+    assert rel_err(out.cpu().numpy(), x.numpy()) < TOL_CHAIN
+
+
 def test_reffwave_rounds_match_oracle_composition(mini, dh, dev):
     """ReffWave (diffwave_ddpm.py:251-313): num_re rounds of q-sample + one-shot denoise, each round one native chain
     call, against the same composition of the oracle's q_sample / one_shot_denoise on the same noise tensors."""
