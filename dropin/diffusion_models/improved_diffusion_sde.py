@@ -1,2 +1,2 @@
-"""Drop-in for ``diffusion_models/improved_diffusion_sde.py`` (RevImprovedDiffusion); the scripts do ``from ... import *``."""
-from audiopure_amd.diffusion_models.improved_diffusion_sde import RevImprovedDiffusion  # noqa: F401
+"""Drop-in for ``diffusion_models/improved_diffusion_sde.py`` (RevVPSDE, RevImprovedDiffusion); the scripts do ``from ... import *``."""
+from audiopure_amd.diffusion_models.improved_diffusion_sde import RevVPSDE, RevImprovedDiffusion  # noqa: F401
