@@ -1,29 +1,28 @@
-"""``AcousticSystem`` — same dispatch as the reference (acoustic_system.py:5-53): defender (wave) ->
-transform -> defender (spec) -> classifier.  The members are the native modules of this package
-(DiffWave / RevDiffWave, MelSpecDB, M5), so the whole defended forward runs in the HIP library."""
+"""``AcousticSystem`` — the reference's dispatch (acoustic_system.py:5-53): a defender that acts either on the waveform
+or on the spectrogram, an optional waveform -> spectrogram transform, then the classifier.  The members are the native
+modules of this package (DiffWave / RevDiffWave / RevImprovedDiffusion, MelSpecDB, M5 / NativeConvNet / KWSModel), so
+the whole defended forward runs in the HIP library; this class only orders the calls."""
 import torch
+
+_STAGE_OF = {"wave": 0, "spec": 1}        # where in the pipeline the defender sits
 
 
 class AcousticSystem(torch.nn.Module):
-
     def __init__(self, classifier: torch.nn.Module, transform, defender: torch.nn.Module = None,
-                 defense_type: str = 'wave'):
+                 defense_type: str = "wave"):
         super().__init__()
-        self.classifier = classifier
-        self.transform = transform
-        self.defender = defender
-        self.defense_type = defense_type
-        if self.defense_type not in ['wave', 'spec']:
-            raise NotImplementedError('argument defense_type should be \'wave\' or \'spec\'!')   # acoustic_system.py:26-27
+        if defense_type not in _STAGE_OF:                                   # same refusal as acoustic_system.py:26-27
+            raise NotImplementedError("argument defense_type should be 'wave' or 'spec'!")
+        self.classifier, self.transform = classifier, transform
+        self.defender, self.defense_type = defender, defense_type
+
+    def _defends_at(self, stage: int, defend) -> bool:
+        # `defend == True` on purpose: the scripts pass booleans, and anything else means "no defense" there too (:35,:45)
+        return defend == True and self.defender is not None and _STAGE_OF.get(self.defense_type, -1) == stage  # noqa: E712
 
     def forward(self, x, defend=True):
-        if defend == True and self.defender is not None and self.defense_type == 'wave':        # :35-38
-            output = self.defender(x)
-        else:
-            output = x
-        if self.transform is not None:                                                           # :41-42
-            output = self.transform(output)
-        if defend == True and self.defender is not None and self.defense_type == 'spec':        # :45-48
-            output = self.defender(output)
-        output = self.classifier(output)                                                         # :51
-        return output
+        signal = self.defender(x) if self._defends_at(0, defend) else x                       # :35-38
+        feats = signal if self.transform is None else self.transform(signal)                  # :41-42
+        if self._defends_at(1, defend):                                                        # :45-48
+            feats = self.defender(feats)
+        return self.classifier(feats)                                                          # :51
