@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaudiopure_hip.so")
+# AUDIOPURE_HIP_LIB: load another build of the same sources (tools/*.py point it at the -DAP_TOOLS library, which adds
+# the timing-only ap_debug_* hooks); every symbol of include/audiopure.h is still required from it.
+LIB_PATH = os.environ.get("AUDIOPURE_HIP_LIB") or os.path.join(_HERE, "lib", "libaudiopure_hip.so")
 
 AP_PREC_F32 = 0
 AP_PREC_BF16 = 1
@@ -148,7 +150,36 @@ def ptr(t) -> int:
         raise NativeError("audiopure_amd ops need device (cuda/HIP) tensors; got a CPU tensor and there is no CPU path")
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise NativeError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels, hipMalloc and stream() bind to the CURRENT device; a pointer from another one would fault or,
+        # with peer access, silently run cross-device with no stream ordering
+        raise NativeError(f"tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                          "enter `with torch.cuda.device(t.device):` (the module entry points do: _native.on_device)")
     return t.data_ptr()
+
+
+def on_device(fn):
+    """Decorator for module entry points: run the call with the HIP device of the first CUDA tensor argument (or of the
+    module's parameters) current, so that streams, allocations and launches of the library all bind to that device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        import torch
+        dev = None
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                dev = a.device
+                break
+        if dev is None and isinstance(self, torch.nn.Module):
+            p = next(self.parameters(), None)
+            if p is not None and p.is_cuda:
+                dev = p.device
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kw)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kw)
+    return wrapper
 
 
 def stream() -> int:

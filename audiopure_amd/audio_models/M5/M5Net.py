@@ -32,6 +32,18 @@ class _M5InputGrad(torch.autograd.Function):
 
 
 class M5(nn.Module):
+    # Class-level defaults: the scripts obtain the classifier by un-pickling a whole module (audio_models/create_model.py:8-17),
+    # which restores __dict__ without running __init__ -- a reference-pickled ``M5Net.M5`` lands here with the reference's
+    # attributes only.
+    _native = None
+    _key = None
+
+    def __getstate__(self):                    # the device handle is rebuilt on demand, never pickled
+        d = dict(self.__dict__)
+        d.pop("_native", None)
+        d.pop("_key", None)
+        return d
+
     def __init__(self, n_input=1, first_kernel_size=80, n_output=35, stride=16, n_channel=32):
         super().__init__()
         if n_input != 1:
@@ -49,8 +61,6 @@ class M5(nn.Module):
         self.bn4 = nn.BatchNorm1d(2 * n_channel)
         self.pool4 = nn.MaxPool1d(4)
         self.fc1 = nn.Linear(2 * n_channel, n_output)
-        self._native = None
-        self._key = None
 
     def _tensors(self):
         ts = []
@@ -84,6 +94,7 @@ class M5(nn.Module):
             self._native, self._key = h, key
         return self._native
 
+    @N.on_device
     def forward(self, x):
         if self.training:
             raise NotImplementedError("audiopure_amd M5: inference only (BatchNorm folded); call .eval()")

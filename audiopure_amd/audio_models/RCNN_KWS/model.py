@@ -63,6 +63,14 @@ class _KwsInputGrad(torch.autograd.Function):
 
 
 class KWSModel(nn.Module):
+    _h = None                                  # class-level defaults: survive un-pickling without __init__
+    _key = None
+
+    def __getstate__(self):                    # the device handle is rebuilt on demand, never pickled
+        d = dict(self.__dict__)
+        d.pop("_h", None)
+        d.pop("_key", None)
+        return d
 
     def __init__(self, in_size=40, hidden_size=64, kernel_size=(20, 5), stride=(8, 2), gru_num_layers=2, num_dirs=2,
                  num_classes=4):
@@ -75,8 +83,6 @@ class KWSModel(nn.Module):
         self.CRNN_model = _CRNN(in_size, hidden_size, kernel_size, stride, gru_num_layers)
         self.attn_layer = _AttnMech(hidden_size * num_dirs)
         self.apply_attn = _ApplyAttn(hidden_size * 2, num_classes)
-        self._h = None
-        self._key = None
 
     def __del__(self):
         try:
@@ -102,6 +108,7 @@ class KWSModel(nn.Module):
             self._h, self._key = h, key
         return self._h
 
+    @N.on_device
     def forward(self, batch, hidden=None):
         """batch: mel-dB spectrogram [B,1,n_mels,T] (or [B,n_mels,T]) -> log-probabilities [B,num_classes]."""
         if self.training:

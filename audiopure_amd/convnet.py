@@ -342,14 +342,28 @@ class NativeConvNet(nn.Module):
     """``NativeConvNet(module)(x)`` == ``module.eval()(x)`` for the reference's 2-D classifiers, computed by the HIP
     library.  The wrapped module keeps owning the parameters (``.module``); call ``refresh()`` after changing them."""
 
+    # class-level defaults: an instance restored without __init__ (copy / pickle of an older object) still works
+    plan = None
+    input_chw = None
+    _dev_weights = None
+    _dev = None
+    _conv_flags = 0
+    _bwd_packed = None
+    _bwd_key = None
+
     def __init__(self, module: nn.Module, input_chw=(1, 32, 32)):
+        """``input_chw=None`` defers the lowering to the first forward (the plan is then traced for that input's
+        [C, H, W]; the scripts' mel32 / mel40 front-ends give 1x32x32 / 1x40x32)."""
         super().__init__()
         self.module = module
-        self.input_chw = tuple(input_chw)
-        self.plan = lower(module, self.input_chw)
-        self._dev_weights = None
-        self._dev = None
-        self._conv_flags = 0
+        self.input_chw = tuple(input_chw) if input_chw is not None else None
+        self.plan = lower(module, self.input_chw) if input_chw is not None else None
+
+    def __getstate__(self):                    # device images / packed weights are rebuilt on demand, never pickled
+        d = dict(self.__dict__)
+        for k in ("_dev_weights", "_packed", "_dev", "_bwd_packed", "_bwd_key", "_zero_vec"):
+            d.pop(k, None)
+        return d
 
     def set_precision(self, mode: str):
         """"f32": fp32 MFMA (default).  "f32s": eligible conv layers on the bf16 MFMA with exactly 3-way-split fp32
@@ -382,6 +396,7 @@ class NativeConvNet(nn.Module):
         torch.cuda.synchronize(dev)
         self._dev_weights, self._packed, self._dev = W, packed, dev
 
+    @N.on_device
     def forward(self, x):
         if self.training:
             raise NotImplementedError("NativeConvNet: inference only (BatchNorm folded); call .eval()")
@@ -391,10 +406,14 @@ class NativeConvNet(nn.Module):
 
     def _run(self, x):
         """-> (output, every buffer of the plan) -- the backward pass needs the intermediate activations."""
-        if x.dim() != 4 or tuple(x.shape[1:]) != self.input_chw:
-            raise ValueError(f"expected [B, {self.input_chw}], got {tuple(x.shape)}")
         if not x.is_cuda:
             raise N.NativeError("NativeConvNet needs a HIP device tensor; there is no CPU path")
+        if self.plan is None and x.dim() == 4:                   # deferred lowering (input_chw=None)
+            self.input_chw = tuple(x.shape[1:])
+            self.plan = lower(self.module, self.input_chw)
+            self._dev_weights = None
+        if x.dim() != 4 or tuple(x.shape[1:]) != self.input_chw:
+            raise ValueError(f"expected [B, {self.input_chw}], got {tuple(x.shape)}")
         dev = x.device
         if self._dev_weights is None or self._dev != dev:
             self._prepare(dev)

@@ -125,15 +125,19 @@ __global__ void pool2d_bwd_kernel(const float *__restrict__ x, const float *__re
 }
 
 // votes of a batch of score rows into a running histogram (certified_robust.py:58-65: argmax per sample, then a
-// per-class count); first maximum wins like Tensor.max
+// per-class count); first maximum wins like Tensor.max.  A row with a NaN or an infinity is not a vote: it is counted in
+// slot K so the caller can refuse the batch instead of certifying on a numerically broken classifier / denoiser.
 __global__ void argmax_hist_kernel(const float *__restrict__ scores, long long *__restrict__ counts, int B, int K) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float *r = scores + (size_t)b * K;
   int am = 0;
-  for (int k = 1; k < K; k++)
+  bool finite = true;
+  for (int k = 0; k < K; k++) {
+    finite = finite && (fabsf(r[k]) <= 3.402823466e38f);       // false for NaN and +-inf
     if (r[k] > r[am]) am = k;
-  atomicAdd(reinterpret_cast<unsigned long long *>(counts + am), 1ull);
+  }
+  atomicAdd(reinterpret_cast<unsigned long long *>(counts + (finite ? am : K)), 1ull);
 }
 
 }  // namespace ap

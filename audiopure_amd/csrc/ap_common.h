@@ -22,6 +22,21 @@ int hip_fail(hipError_t e, const char *what);
     if (_e != hipSuccess) return ap::hip_fail(_e, #x); \
   } while (0)
 
+// Timing-only hooks (ablation masks, phase stamps, dispatch overrides: tools/*.py) exist only in a -DAP_TOOLS build
+// (`python __graft_entry__.py --tools` -> lib/libaudiopure_hip_tools.so).  The shipped library has no `ablate` kernel
+// argument, no ap_debug_* symbol and no stamped instantiation.
+#ifdef AP_TOOLS
+#define AP_ABLATE_PARAM , int ablate
+#define AP_ABLATE_ARG(x) , (x)
+#define AP_ABLATE_DECL
+#define AP_TOOLS_VAR static int
+#else
+#define AP_ABLATE_PARAM
+#define AP_ABLATE_ARG(x)
+#define AP_ABLATE_DECL constexpr int ablate = 0;
+#define AP_TOOLS_VAR static constexpr int
+#endif
+
 constexpr int TT = 128;   // time-tile (samples) of the fused kernels
 constexpr int KC = 32;    // channels per staged K-chunk of the dilated conv (x3 taps = 96 K rows)
 

@@ -681,6 +681,7 @@ __global__ void pool2d_kernel(const float *__restrict__ x, float *__restrict__ y
 
 using namespace ap;
 
+#ifdef AP_TOOLS
 static int g_conv_no_frag = 0;     // ap_debug_conv_path(1): timing A/B against the LDS-staged 128 x 128 kernel
 static long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
 extern "C" int ap_debug_conv_path(int no_frag) {
@@ -688,6 +689,10 @@ extern "C" int ap_debug_conv_path(int no_frag) {
   else g_conv_no_frag = no_frag;
   return 0;
 }
+#else
+static constexpr int g_conv_no_frag = 0;
+static constexpr long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
+#endif
 
 // layers the streamed-weight kernel serves carry a second image behind the first
 static bool conv_has_frag(int Cout, int Cin_g, int groups) { return Cin_g % 16 == 0 && Cout / groups >= 64; }

@@ -260,7 +260,8 @@ template <int C, int TTK>
 __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int ablate) {
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles AP_ABLATE_PARAM) {
+  AP_ABLATE_DECL
   using G = RBGeom<C, TTK>;
   constexpr int TT = TTK;   // time tile of this kernel (shadows ap::TT)
   constexpr int NT = G::NT;
@@ -506,9 +507,11 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
   }
 }
 
-static int g_tile = 64;    // time tile of the residual-block kernel: 128 (8 waves, 1 WG/CU) or 64 (4 waves, 2 WG/CU)
-static int g_force_f32 = 0;  // debug: run the fp32 kernel even in a bf16 context (A/B timing in one process)
-static int g_ablate = 0;   // timing-only ablation mask (ap_debug_ablate); 0 in every real run
+AP_TOOLS_VAR g_tile = 64;    // time tile of the residual-block kernel: 64 (4 waves, 2 WG/CU); 128 (8 waves, 1 WG/CU) in tools builds
+AP_TOOLS_VAR g_force_f32 = 0;  // tools builds: run the fp32 kernel even in a bf16 context (A/B timing in one process)
+#ifdef AP_TOOLS
+static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
+#endif
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                     int accumulate, int B, int L, hipStream_t st) {
@@ -556,7 +559,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   }
 #define AP_RB(CC, TK)                                                                                              \
   resblock_f32_kernel<CC, TK><<<(unsigned)B * ((L + TK - 1) / TK), CC / 64 * TK, 0, st>>>(                         \
-      hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, (L + TK - 1) / TK, g_ablate)
+      hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, (L + TK - 1) / TK AP_ABLATE_ARG(g_ablate))
   const int tk = g_tile;
   if (C == 64 && tk == 64) AP_RB(64, 64);
   else if (C == 64) AP_RB(64, 128);
@@ -829,6 +832,7 @@ __global__ void philox_fill_kernel(float *__restrict__ out, uint64_t seed, uint3
 
 }  // namespace ap
 
+#ifdef AP_TOOLS
 extern "C" int ap_debug_tile(int tile) {
   if (tile != 64 && tile != 128) return -22;
   ap::g_tile = tile;
@@ -853,6 +857,7 @@ extern "C" int ap_debug_ablate(int mask) {
   ap::g_ablate_bf16 = mask;
   return 0;
 }
+#endif  // AP_TOOLS
 
 extern "C" int ap_nes_perturb(const float *x, float *out, float sigma, uint64_t seed, uint32_t draw, int A, int S,
                               int lead, int L, void *stream) {

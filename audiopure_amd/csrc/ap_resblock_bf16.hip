@@ -99,8 +99,9 @@ template <int C, bool X4, bool E4, bool TRACE, int DBG = 0>
 __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const __bf16 *__restrict__ w1p, const float *__restrict__ b1, const __bf16 *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk, int ablate,
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, int nblk AP_ABLATE_PARAM,
     unsigned long long *__restrict__ trace) {
+  AP_ABLATE_DECL
   constexpr int NW = C / 32, NT = NW * 64, NCH = C / BKC;
   static_assert(NT == 512, "bf16 kernel is built for C = 256 (8 waves)");
   constexpr int GSTRIDE = C + 8;                               // bf16 per column row of the g image (528 B)
@@ -532,8 +533,10 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   mark(9);
 }
 
+#ifdef AP_TOOLS
 int g_ablate_bf16 = 0;
 unsigned long long *g_trace_bf16 = nullptr;   // ap_debug_trace: device buffer of nblk x 2 x 16 timestamps, or null
+#endif
 
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st) {
@@ -552,8 +555,10 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
   const bool e4 = (L % 4 == 0) && L >= 4, x4 = e4 && (d % 4 == 0);
 #define AP_BF16_LAUNCH(X4, E4, TR)                                                                                  \
   resblock_bf16_kernel<256, X4, E4, TR><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, \
-                                                                        accumulate, ntiles, nblk, g_ablate_bf16,     \
-                                                                        g_trace_bf16)
+                                                                        accumulate, ntiles, nblk                     \
+                                                                        AP_ABLATE_ARG(g_ablate_bf16), AP_TRACE_BUF)
+#ifdef AP_TOOLS
+#define AP_TRACE_BUF g_trace_bf16
   if (g_trace_bf16 && x4) {
     switch ((g_ablate_bf16 >> 6) & 3) {
       case 1: resblock_bf16_kernel<256, true, true, true, 1><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, g_trace_bf16); break;
@@ -562,10 +567,15 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
       default: AP_BF16_LAUNCH(true, true, true);
     }
   }
-  else if (x4) AP_BF16_LAUNCH(true, true, false);
+  else
+#else
+#define AP_TRACE_BUF nullptr
+#endif
+  if (x4) AP_BF16_LAUNCH(true, true, false);
   else if (e4) AP_BF16_LAUNCH(false, true, false);
   else AP_BF16_LAUNCH(false, false, false);
 #undef AP_BF16_LAUNCH
+#undef AP_TRACE_BUF
   AP_HIP(hipGetLastError());
   return 0;
 }

@@ -547,7 +547,9 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
   mark(14);
 }
 
+#ifdef AP_TOOLS
 extern unsigned long long *g_trace_bf16;
+#endif
 
 int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st) {
@@ -563,10 +565,13 @@ int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float
   const _Float16 *w2p = (const _Float16 *)ctx->w2p_h + (size_t)layer * (C + S) * C * 2;
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
+#ifdef AP_TOOLS
   if (L % 4 == 0 && L >= 4 && g_trace_bf16)
     resblock_f32h_kernel<256, true, true><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
                                                                          accumulate, ntiles, nblk, g_trace_bf16);
-  else if (L % 4 == 0 && L >= 4)
+  else
+#endif
+  if (L % 4 == 0 && L >= 4)
     resblock_f32h_kernel<256, true, false><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d,
                                                                           accumulate, ntiles, nblk, nullptr);
   else

@@ -123,6 +123,14 @@ class NativeEngine:
 
 
 class WaveNet_Speech_Commands(nn.Module):
+    _engine = None                             # class-level defaults: survive copy / un-pickling without __init__
+    _precision = N.AP_PREC_F32
+
+    def __getstate__(self):                    # the native context (device weights, workspace) is rebuilt on demand
+        d = dict(self.__dict__)
+        d.pop("_engine", None)
+        return d
+
     def __init__(self, in_channels=1, res_channels=256, skip_channels=128, out_channels=1,
                  num_res_layers=30, dilation_cycle=10,
                  diffusion_step_embed_dim_in=128,
@@ -172,6 +180,7 @@ class WaveNet_Speech_Commands(nn.Module):
         ts += [f0.bias, f0.weight_g, f0.weight_v, f2.weight, f2.bias]
         return ts
 
+    @N.on_device
     def engine(self) -> NativeEngine:
         """Fold + pack the current parameters into the native context (re-done when any parameter changed)."""
         ts = self._blob_tensors()
@@ -191,16 +200,16 @@ class WaveNet_Speech_Commands(nn.Module):
 
     @staticmethod
     def _check_input(x: torch.Tensor):
-        if torch.is_grad_enabled() and x.requires_grad:
-            raise NotImplementedError(
-                "audiopure_amd: gradient through the purifier is not implemented (forward-only HIP path; "
-                "SURVEY.md section 8f).  Call under torch.no_grad() or detach the input.")
         if x.dim() != 3 or x.shape[1] != 1:
             raise ValueError(f"expected audio of shape [B,1,L], got {tuple(x.shape)}")
 
+    @N.on_device
     def eps(self, x: torch.Tensor, step: float) -> torch.Tensor:
         """eps_theta(x, step) for a step shared by the batch."""
         self._check_input(x)
+        if torch.is_grad_enabled() and x.requires_grad:          # d eps / d audio on the HIP library (parameters frozen)
+            from .._grad import differentiable_eps
+            return differentiable_eps(self, x, float(step))
         eng = self.engine()
         x = x.detach().float().contiguous()
         B, _, L = x.shape

@@ -92,6 +92,11 @@ class EpsGrad:
         N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(packed), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, 1, L, Cout, 1, kw, 1,
                                   pad, 1, fl, Cin, 0, N.stream()), "ap_conv2d_fwd")
 
+    def eps_only(self, x: torch.Tensor, step: float):
+        """The plain fused forward (``ap_eps_fwd``): what the chain's forward pass calls -- nothing is kept."""
+        with torch.no_grad():
+            return self.net.eps(x.detach(), step)
+
     # ---- one eps evaluation, keeping what its backward needs ---------------------------------------------------
     def forward_save(self, x: torch.Tensor, step: float):
         eng = self._prepare()
@@ -153,25 +158,43 @@ class EpsGrad:
         return dx
 
 
+def _axpby(x, y, a, b):
+    """a x + b y on the library (``ap_axpbyc``); y None -> a x.  Shapes may differ as long as the element counts agree."""
+    x = x if x.is_contiguous() else x.contiguous()
+    if y is not None:
+        y = y.float()
+        y = y if y.is_contiguous() else y.contiguous()
+        assert y.numel() == x.numel()
+    out = torch.empty_like(x)
+    N.check(N.lib().ap_axpbyc(N.ptr(x), N.ptr(y), N.ptr(out), float(a), float(b) if y is not None else 0.0, 0.0, x.numel(),
+                              N.stream()), "ap_axpbyc")
+    return out
+
+
 class _ChainFn(torch.autograd.Function):
-    """x_out = chain(x_in): q-sample then the links (step, ca, cb, cs); noise tensors given explicitly."""
+    """x_out = chain(x_in): q-sample then the links (step, ca, cb, cs); noise tensors given explicitly.
+
+    The forward pass keeps only the state entering each link: its eps-evaluations run without per-layer saves
+    (``grad.eps_only`` = the plain fused forward) and every elementwise update is an ``ap_axpbyc`` call.  The backward
+    pass recomputes one evaluation per link with saves (``grad.forward_save``) and applies its J^T."""
 
     @staticmethod
     def forward(ctx, x, grad, steps, qa, qs, zs):
-        """zs[k] = draw k of the chain ([B,1,L]); draw 0 is the q-sample's (the numbering of ap_purify_chain)."""
+        """zs[k] = draw k of the chain ([B,1,L] or [B,L]); draw 0 is the q-sample's (the numbering of ap_purify_chain)."""
         xs = []
         cur = x.detach().float().contiguous()
-        if qs != 0.0:
-            cur = qa * cur + qs * zs[0]
-        elif qa != 1.0:
-            cur = qa * cur
+        eps_only = getattr(grad, "eps_only", None)
         with torch.no_grad():
+            if qs != 0.0:
+                cur = _axpby(cur, zs[0], qa, qs)
+            elif qa != 1.0:
+                cur = _axpby(cur, None, qa, 0.0)
             for (t, ca, cb, cs, draw) in steps:
                 xs.append(cur)
-                eps, _ = grad.forward_save(cur, t)
-                nxt = ca * cur + cb * eps
+                eps = eps_only(cur, t) if eps_only is not None else grad.forward_save(cur, t)[0]
+                nxt = _axpby(cur, eps, ca, cb)
                 if cs != 0.0 and draw:
-                    nxt = nxt + cs * zs[draw]
+                    nxt = _axpby(nxt, zs[draw], 1.0, cs)
                 cur = nxt
         ctx.grad, ctx.steps, ctx.qa, ctx.xs = grad, steps, qa, xs
         return cur
@@ -182,13 +205,41 @@ class _ChainFn(torch.autograd.Function):
         with torch.no_grad():
             for (t, ca, cb, cs, draw), xt in zip(reversed(ctx.steps), reversed(ctx.xs)):
                 _, saved = ctx.grad.forward_save(xt, t)          # recompute this link's evaluation (adjoint-style)
-                g = ca * g + cb * ctx.grad.backward(saved, g)
+                g = _axpby(g, ctx.grad.backward(saved, g), ca, cb)
                 del saved
-        return ctx.qa * g, None, None, None, None, None
+            if ctx.qa != 1.0:
+                g = _axpby(g, None, ctx.qa, 0.0)
+        return g, None, None, None, None, None
+
+
+class _EpsFn(torch.autograd.Function):
+    """eps_theta(x, t) with its input gradient (the reference's network is plain differentiable torch, WaveNet.py:164-172)."""
+
+    @staticmethod
+    def forward(ctx, x, grad, step):
+        with torch.no_grad():
+            eps, saved = grad.forward_save(x.detach().float().contiguous(), step)
+        ctx.grad, ctx.saved = grad, saved
+        return eps
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.no_grad():
+            dx = ctx.grad.backward(ctx.saved, g.detach().float().contiguous())
+        ctx.saved = None
+        return dx, None, None
+
+
+def _eps_grad_of(net):
+    if getattr(net, "_eps_grad", None) is None or net._eps_grad.net is not net:
+        net._eps_grad = EpsGrad(net)
+    return net._eps_grad
 
 
 def differentiable_chain(net, x, steps, qa, qs, zs):
     """The sampling chain as an autograd node (gradient with respect to ``x`` only)."""
-    if not hasattr(net, "_eps_grad"):
-        net._eps_grad = EpsGrad(net)
-    return _ChainFn.apply(x, net._eps_grad, list(steps), float(qa), float(qs), zs)
+    return _ChainFn.apply(x, _eps_grad_of(net), list(steps), float(qa), float(qs), zs)
+
+
+def differentiable_eps(net, x, step):
+    return _EpsFn.apply(x, _eps_grad_of(net), float(step))

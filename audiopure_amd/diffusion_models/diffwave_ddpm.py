@@ -70,6 +70,8 @@ class DiffWave(torch.nn.Module):
         assert x.ndim == 3                                                  # diffwave_ddpm.py:62,89
         dev = next(self.model.parameters()).device
         self.model._check_input(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return x.to(dev).float()         # stays in the graph: _chain makes the sampling chain an autograd node
         return x.detach().to(dev).float().contiguous()
 
     def _tables(self):
@@ -80,8 +82,12 @@ class DiffWave(torch.nn.Module):
         eng.set_schedule(dh)
         return eng
 
+    @N.on_device
     def _chain(self, x, steps, qa=1.0, qs=0.0, n_draws=0):
-        """Run ap_purify_chain over the batch in workspace-sized chunks."""
+        """Run ap_purify_chain over the batch in workspace-sized chunks.  An input that requires grad (outside
+        ``forward``, which is ``no_grad`` like the reference's) goes through the recompute-based autograd node instead."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            return self._chain_grad(x, steps, qa, qs, n_draws)
         eng = self._tables()
         B, _, L = x.shape
         z_all, seed, off = self._draws(n_draws, x)
@@ -94,6 +100,22 @@ class DiffWave(torch.nn.Module):
                                             seed, off + s, N.ptr(out[s:e]), e - s, L, ws.data_ptr(), ws.numel(),
                                             N.stream()), "ap_purify_chain")
         return out
+
+    @N.on_device
+    def _chain_grad(self, x, steps, qa=1.0, qs=0.0, n_draws=0):
+        """The same chain as an autograd node (gradient with respect to the audio; ``_grad.py``).  The reference's
+        ``_reverse`` / ``one_shot_denoise`` / ... are plain differentiable torch code (diffwave_ddpm.py:75-104,174-194) and
+        its SDE runner re-integrates backwards (diffwave_sde.py:200-204); here states are check-pointed per link and each
+        link's eps-evaluation is recomputed in the backward pass."""
+        from ._grad import differentiable_chain
+        self._tables()
+        B, _, L = x.shape
+        z_all, seed, off = self._draws(n_draws, x.detach())
+        if z_all is None and n_draws:                            # in-kernel Philox stream: materialise the same draws
+            z_all = torch.empty((n_draws, B, L), device=x.device)
+            for k in range(n_draws):
+                N.check(N.lib().ap_philox_normal(N.ptr(z_all[k]), seed, k, off, B, L, N.stream()), "ap_philox_normal")
+        return differentiable_chain(self.model, x, steps, qa, qs, z_all)
 
     def _ddpm_steps(self, t_star):
         dh = self.diffusion_hyperparams
@@ -110,10 +132,10 @@ class DiffWave(torch.nn.Module):
 
     # ---- reference surface ------------------------------------------------------------------
     def forward(self, waveforms: Union[torch.Tensor, np.ndarray]):
-        x0 = self._prep(waveforms)
         t_star = int(self.reverse_timestep)
         ab = float(self.diffusion_hyperparams["Alpha_bar"][t_star - 1].double())
-        with torch.no_grad():                                                # :41-43
+        with torch.no_grad():                                                # :41-43 (the output is detached there too)
+            x0 = self._prep(waveforms)
             return self._chain(x0, self._ddpm_steps(t_star), math.sqrt(ab), math.sqrt(1.0 - ab), n_draws=t_star)
 
     def _diffusion(self, x_0):
@@ -131,6 +153,7 @@ class DiffWave(torch.nn.Module):
             return self._chain(x, self._ddpm_steps(t_star), n_draws=t_star)
         return self._chain(x, self._ddpm_steps(t_star), n_draws=t_star)
 
+    @N.on_device
     def compute_coefficients(self, x_t, t: int):
         """-> (eps_theta, mu_theta, sigma_theta) at timestep t (diffwave_ddpm.py:143-164)."""
         x = self._prep(x_t)
@@ -138,6 +161,8 @@ class DiffWave(torch.nn.Module):
         dh = self.diffusion_hyperparams
         a, ab = float(dh["Alpha"][t].double()), float(dh["Alpha_bar"][t].double())
         ca, cb = 1.0 / math.sqrt(a), -(1.0 - a) / math.sqrt(1.0 - ab) / math.sqrt(a)
+        if torch.is_grad_enabled() and x.requires_grad:          # differentiable in the reference (:143-164)
+            return self.model.eps(x, float(t)), self._chain(x, [(float(t), ca, cb, 0.0, 0)]), dh["Sigma"][t]
         eps, mu = torch.empty_like(x), torch.empty_like(x)
         B, _, L = x.shape
         for s, e in eng.chunks(B):

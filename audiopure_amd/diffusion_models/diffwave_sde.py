@@ -6,8 +6,13 @@ scheme runs as one native sampling chain (ap_purify_chain): per k = t*-1..0
     x <- x (1 + b_k/2) - b_k eps(x,k)/sqrt(1-ac_k) + sqrt(b_k) sqrt((1-ac_{k-1})/(1-ac_k)) z   (0 at k=0)
 
 (SURVEY.md Appendix A.3).  torchsde is not needed.  Deviations, documented: exactly t* epsilon
-evaluations (the reference's fp32 time stepping adds a spurious ~6e-8-long extra step for t* >= 10);
-forward only — autograd through the purifier raises.
+evaluations (the reference's fp32 time stepping adds a spurious ~6e-8-long extra step for t* >= 10).
+``rand_t`` follows the reference (diffwave_sde.py:186-194): the q-sample level is ``t + randint(-t_delta, t_delta)``
+while the reverse integration always runs ``args.t`` Euler steps (``t0 = 1 - args.t/T``).  ``use_bm`` is accepted and
+has no effect: the reference only uses it to hand torchsde a pre-built ``BrownianInterval`` (:198-200), which changes how
+the increments are drawn, not their law; here the increments come from the noise source of the wrapped ``DiffWave``.
+With ``x.requires_grad`` the chain is an autograd node (``_grad.py``): gradients reach the audio, as through the
+reference's ``sdeint_adjoint``.
 """
 from __future__ import annotations
 
@@ -123,6 +128,7 @@ class RevDiffWave(torch.nn.Module):
         self.betas = self.rev_vpsde.discrete_betas.float()
         return self
 
+    @N.on_device
     def audio_editing_sample(self, audio):
         assert isinstance(audio, torch.Tensor)
         assert audio.ndim == 3, audio.ndim
@@ -139,8 +145,8 @@ class RevDiffWave(torch.nn.Module):
                     total_noise_levels = self.args.t + np.random.randint(-self.args.t_delta, self.args.t_delta)
                     print(f'total_noise_levels: {total_noise_levels}')
                 a = float(self.rev_vpsde.alphas_cumprod[total_noise_levels - 1].double())     # :189-190
-                steps = self.rev_vpsde.euler_steps(total_noise_levels)
-                x0 = self.model._chain(x0, steps, math.sqrt(a), math.sqrt(1.0 - a), n_draws=total_noise_levels + 1)
+                steps = self.rev_vpsde.euler_steps(self.args.t)       # :192-193: args.t steps whatever level was drawn
+                x0 = self.model._chain(x0, steps, math.sqrt(a), math.sqrt(1.0 - a), n_draws=self.args.t + 1)
                 xs.append(x0)
         return torch.cat(xs, dim=0)
 
@@ -148,28 +154,19 @@ class RevDiffWave(torch.nn.Module):
         """The same Euler chain as an autograd node: the white-box attack's ``loss.backward()`` reaches the audio
         (white_box_attack.py:392,437-439; the reference gets there through sdeint_adjoint, diffwave_sde.py:200-204).
         States are check-pointed per step and each step's eps-evaluation is recomputed in the backward pass."""
-        from ._grad import differentiable_chain
         if audio.dim() != 3 or audio.shape[1] != 1:
             raise ValueError(f"expected audio of shape [B,1,L], got {tuple(audio.shape)}")
         dw = self.model
-        dev = next(dw.model.parameters()).device
-        x = audio.to(dev).float()
+        x = audio.to(next(dw.model.parameters()).device).float()
         xs = []
         for it in range(self.args.sample_step):
             total_noise_levels = self.args.t
             if self.args.rand_t:
                 total_noise_levels = self.args.t + np.random.randint(-self.args.t_delta, self.args.t_delta)
+                print(f'total_noise_levels: {total_noise_levels}')
             a = float(self.rev_vpsde.alphas_cumprod[total_noise_levels - 1].double())
-            steps = self.rev_vpsde.euler_steps(total_noise_levels)
-            dw._tables()
-            z_all, seed, off = dw._draws(total_noise_levels + 1, x.detach())
-            if z_all is None:                                    # in-kernel Philox stream: materialise the same draws
-                B, _, L = x.shape
-                z_all = torch.empty((total_noise_levels + 1, B, L), device=dev)
-                for k in range(total_noise_levels + 1):
-                    N.check(N.lib().ap_philox_normal(N.ptr(z_all[k]), seed, k, off, B, L, N.stream()), "ap_philox_normal")
-            zs = z_all.reshape(z_all.shape[0], x.shape[0], 1, x.shape[2])
-            x = differentiable_chain(dw.model, x, steps, math.sqrt(a), math.sqrt(1.0 - a), zs)
+            steps = self.rev_vpsde.euler_steps(self.args.t)
+            x = dw._chain_grad(x, steps, math.sqrt(a), math.sqrt(1.0 - a), n_draws=self.args.t + 1)
             xs.append(x)
         return torch.cat(xs, dim=0)
 

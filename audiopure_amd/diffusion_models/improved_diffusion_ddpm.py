@@ -48,6 +48,7 @@ class ImprovedDiffusionDDPM(torch.nn.Module):
             return self._noise.pop(0).to(like.device).float().reshape(like.shape).contiguous()
         return torch.randn_like(like)
 
+    @N.on_device
     def forward(self, img):
         assert isinstance(img, torch.Tensor) and img.ndim == 4
         if torch.is_grad_enabled() and img.requires_grad:

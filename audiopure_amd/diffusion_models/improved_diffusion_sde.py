@@ -128,6 +128,7 @@ class RevImprovedDiffusion(torch.nn.Module):
             return self._noise.pop(0).to(like.device).float().reshape(like.shape)
         return torch.randn_like(like)
 
+    @N.on_device
     def image_editing_sample(self, img):
         assert isinstance(img, torch.Tensor)
         assert img.ndim == 4, img.ndim

@@ -52,6 +52,18 @@ class Upsample(nn.Module):
 
 
 class UNetModel(nn.Module):
+    _packed = None                             # class-level defaults: survive copy / un-pickling without __init__
+    _key = None
+    _tape = None
+    _conv_flags = 0
+
+    def __getstate__(self):                    # packed device images and the tape are rebuilt on demand, never pickled
+        d = dict(self.__dict__)
+        for k in ("_packed", "_key", "_tape"):
+            d.pop(k, None)
+        d["_packed_t"] = {}
+        return d
+
     def __init__(self, in_channels=1, model_channels=128, out_channels=1, num_res_blocks=3,
                  attention_resolutions=(2, 4), dropout=0, channel_mult=(1, 2, 2, 2), conv_resample=True, dims=2,
                  num_classes=None, use_checkpoint=False, num_heads=4, num_heads_upsample=-1,
@@ -187,12 +199,14 @@ class UNetModel(nn.Module):
                 raise NotImplementedError(type(layer).__name__)
         return h
 
+    @N.on_device
     def forward(self, x, timesteps, y=None):
         assert y is None, "class conditioning is not built"
         if torch.is_grad_enabled() and x.requires_grad:
             return _UNetInputGrad.apply(x, self, timesteps)       # white-box attack: d/dx on the HIP path (input_grad)
         return self._forward(x, timesteps)
 
+    @N.on_device
     def forward_save(self, x, timesteps):
         """One evaluation that also records what its input gradient needs: (eps, tape)."""
         self._tape = []
@@ -252,6 +266,7 @@ class UNetModel(nn.Module):
             self._packed_t[m] = img
         return self._packed_t[m]
 
+    @N.on_device
     def input_grad(self, tape, dout):
         """J^T dout of the evaluation ``tape`` came from (parameters and the timestep embedding are constants)."""
         lib, st = N.lib(), N.stream

@@ -29,9 +29,13 @@ class NES(nn.Module):
         self.samples_per_draw_batch_size = samples_per_draw_batch
         self.sigma = sigma
         self.EOT_wrapper = EOT_wrapper
-        self.seed = 0
+        # Philox key of this estimator's perturbations.  FAKEBOB builds a fresh NES on every attack iteration
+        # (black_box_attack.py:181) and the reference draws fresh torch.randn each time, so the key must differ from
+        # instance to instance: it is drawn from torch's global generator ("seed torch, get reproducible output").
+        self.seed = int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
         self._draw = 0
 
+    @N.on_device
     def forward(self, x, y):
         n_audios, n_channels, Nn = x.shape
         assert n_channels == 1

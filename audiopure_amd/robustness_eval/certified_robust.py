@@ -18,14 +18,15 @@ from scipy.stats import beta, norm
 
 from .. import _native as N
 from ..diffusion_models.diffwave_ddpm import DiffWave
+from ..lowering import lower_classifier, lower_transform
 
 
 class RobustCertificate():
 
     def __init__(self, classifier: torch.nn.Module, transform=None, denoiser=None, one_shot_rev: bool = False,
                  num_classes=10) -> None:
-        self.classifier = classifier
-        self.transform = transform
+        self.classifier = lower_classifier(classifier)       # un-pickled reference modules / torchaudio Compose -> native
+        self.transform = lower_transform(transform)
         self.denoiser = denoiser
         self.num_classes = num_classes
         self.one_shot_rev = one_shot_rev
@@ -33,6 +34,7 @@ class RobustCertificate():
         self.native_batch = 512            # samples per device batch when the caller's batch_size is smaller
 
     @torch.no_grad()
+    @N.on_device
     def forward(self, x: torch.Tensor):                                      # certified_robust.py:17-31
         x_in = x
         if self.denoiser is not None:
@@ -68,12 +70,13 @@ class RobustCertificate():
         return out
 
     @torch.no_grad()
+    @N.on_device
     def smooth_predict(self, x: torch.Tensor, num_sampling: int = 100, sigma=0.25, batch_size=64):
         assert (x.shape[0] == 1)                                             # :36
         dev = next(self.classifier.parameters()).device
         x = x.to(dev).float().reshape(1, 1, -1)
         step = max(int(batch_size), int(self.native_batch))
-        counts = torch.zeros(self.num_classes, dtype=torch.int64, device=dev)
+        counts = torch.zeros(self.num_classes + 1, dtype=torch.int64, device=dev)      # last slot: non-finite score rows
         done = 0
         while done < num_sampling:
             nb = min(step, num_sampling - done)
@@ -86,9 +89,14 @@ class RobustCertificate():
             N.check(N.lib().ap_argmax_hist(N.ptr(scores), counts.data_ptr(), nb, self.num_classes, N.stream()),
                     "ap_argmax_hist")
             done += nb
-        return counts.cpu()
+        counts = counts.cpu()
+        if int(counts[-1]) != 0:
+            raise FloatingPointError(f"smooth_predict: {int(counts[-1])} of {num_sampling} score rows are not finite "
+                                     "(classifier or denoiser produced NaN/inf); refusing to count them as votes")
+        return counts[:-1]
 
     @torch.no_grad()
+    @N.on_device
     def certify(self, x: torch.Tensor, y: torch.Tensor, sigma: float = 0.25, n_0: int = 100, n: int = 100000,
                 alpha: float = 0.001, batch_size: int = 64):                 # :67-97
         y_pred, radius = -torch.ones_like(y), torch.zeros_like(y, dtype=torch.float32)

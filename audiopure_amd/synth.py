@@ -157,3 +157,28 @@ def noise(draw: int, B: int, L: int = 16000, seed: int = 1234, utt_offset: int =
     for i in range(B):
         out[i, 0] = normal(f"z/{draw}/{utt_offset + i}", (L,), seed)
     return out
+
+
+def synth_init(model, seed: int = 0):
+    """Deterministic, torch-RNG-independent weights keyed on the state-dict names (He-scaled convs, BN statistics away
+    from the identity so the fold is exercised)."""
+    import torch
+    sd = {}
+    for k, v in model.state_dict().items():
+        shape = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(100)
+        elif k.endswith("running_var"):
+            sd[k] = torch.from_numpy(uniform("cn/" + k, shape, seed, 0.5, 1.5))
+        elif k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(uniform("cn/" + k, shape, seed, -0.2, 0.2))
+        elif v.dim() >= 2:
+            fan_in = v[0].numel()
+            a = (6.0 / fan_in) ** 0.5
+            sd[k] = torch.from_numpy(uniform("cn/" + k, shape, seed, -a, a))
+        elif k.endswith("weight"):                       # BN gamma
+            sd[k] = torch.from_numpy(uniform("cn/" + k, shape, seed, 0.7, 1.3))
+        else:                                            # biases / BN beta
+            sd[k] = torch.from_numpy(uniform("cn/" + k, shape, seed, -0.1, 0.1))
+    model.load_state_dict(sd)
+    return model.eval()

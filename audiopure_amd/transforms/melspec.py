@@ -42,6 +42,7 @@ class MelSpecDB(torch.nn.Module):
         super().__init__()
         self.n_mels = n_mels
 
+    @N.on_device
     def forward(self, x):
         if torch.is_grad_enabled() and x.requires_grad:
             if self.mode != 0:
@@ -92,6 +93,7 @@ class MelSpecDBHTK(torch.nn.Module):
         super().__init__()
         self.n_mels = n_mels
 
+    @N.on_device
     def forward(self, x):
         lead = x.shape[:-1]
         L = x.shape[-1]

@@ -327,7 +327,8 @@ int ap_nes_perturb(const float *x, float *out, float sigma, uint64_t seed, uint3
                    void *stream);
 int ap_nes_grad(const float *loss, float *grad, uint64_t seed, uint32_t draw, int A, int S, int L, int accumulate,
                 void *stream);
-/* counts[argmax_k scores[b][k]] += 1 for b < B (int64 device histogram; certified_robust.py:58-65) */
+/* counts[argmax_k scores[b][k]] += 1 for b < B (int64 device histogram of K + 1 slots; certified_robust.py:58-65).
+ * Rows holding a NaN or an infinity are not votes: they are counted in slot K. */
 int ap_argmax_hist(const float *scores, long long *counts, int B, int K, void *stream);
 /* pieces of the input gradient of the lowered 2-D classifiers (audiopure_amd/convnet.py): slice accumulate, backward
  * through a fused ReLU, zero insertion for the transposed conv of a strided conv (the conv itself is ap_conv2d_fwd on

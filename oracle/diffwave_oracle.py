@@ -172,6 +172,41 @@ def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list) -> torc
     return x
 
 
+def ddpm_reverse(w, cfg, dh, x_t: torch.Tensor, t_star: int, noises: list) -> torch.Tensor:
+    """``DiffWave._reverse`` (diffwave_ddpm.py:75-104) on an already noised input: noises[k] = k-th reverse draw (t > 0)."""
+    with torch.no_grad():
+        x, k = x_t.clone(), 0
+        for t in range(t_star - 1, -1, -1):
+            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t)
+            if t > 0:
+                x = mu + sigma * noises[k]
+                k += 1
+            else:
+                x = mu
+    return x
+
+
+def fast_reverse(w, cfg, dh, x_t: torch.Tensor, t_star: int, noises: list, K: int = 3) -> torch.Tensor:
+    """``DiffWave.fast_reverse`` (diffwave_ddpm.py:106-141): K respaced steps S = round(linspace(1, t*, K)) - 1 with the
+    respaced alpha / alpha-bar tables; the reference multiplies the noise by the VARIANCE beta~ (not its root, :138) and
+    draws at every step, the last one (beta~ = 0) included -- both kept."""
+    Ab = dh["Alpha_bar"]
+    S = torch.round(torch.linspace(1, t_star, K)).int() - 1                               # :118-119
+    beta, beta_t = torch.zeros(K), torch.zeros(K)
+    for i in range(K):                                                                    # :122-128
+        beta[i] = 1 - Ab[S[i]] / Ab[S[i - 1]] if i > 0 else 1 - Ab[S[i]]
+        beta_t[i] = (1 - Ab[S[i - 1]]) / (1 - Ab[S[i]]) * beta[i] if i > 0 else 0
+    alpha = 1 - beta
+    alpha_bar = torch.cumprod(alpha, dim=0)
+    with torch.no_grad():
+        x = x_t
+        for n, t in enumerate(range(K - 1, -1, -1)):                                      # :133-139
+            eps = eps_net(w, cfg, x, S[t] * torch.ones((x.shape[0], 1)))
+            mu = (x - (1 - alpha[t]) / torch.sqrt(1 - alpha_bar[t]) * eps) / torch.sqrt(alpha[t])
+            x = mu + beta_t[t] * noises[n]
+    return x
+
+
 def one_shot_denoise(w, cfg, dh, x_t: torch.Tensor, t_star: int) -> torch.Tensor:
     """diffwave_ddpm.py:174-205: one eps-eval at t = t*-1, x0_hat = sqrt(1/ab) x - sqrt(1/ab - 1) eps."""
     with torch.no_grad():
@@ -224,15 +259,18 @@ def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int):
     return -drift, scale * diffusion                                                     # :125, :114, :134
 
 
-def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list) -> torch.Tensor:
+def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list, q_level: int | None = None) -> torch.Tensor:
     """``RevDiffWave.audio_editing_sample`` (sample_step = 1) with torchsde's Euler scheme
     ``y <- y + f h + g sqrt(h) z`` restated (torchsde 0.2.5, un-vendored: parity unpinned for
     the loop itself).  h = 1/N; steps k = t*-1 ... 0: exactly t* eps-evaluations (the reference's
-    spurious extra micro-step for t* >= 10 is documented in SURVEY.md A.3 and omitted)."""
+    spurious extra micro-step for t* >= 10 is documented in SURVEY.md A.3 and omitted).
+    ``q_level``: with ``rand_t`` the reference q-samples at ``total_noise_levels = t + randint(...)`` (:186-190) while the
+    integration still starts at ``t0 = 1 - args.t/T`` (:192-193), i.e. runs t* = args.t steps; default q_level = t*."""
     N = tb["N"]
+    q = t_star if q_level is None else q_level
     with torch.no_grad():
         a = (1 - tb["discrete_betas"]).cumprod(dim=0)                                    # :189
-        x = x0 * a[t_star - 1].sqrt() + noises[0] * (1.0 - a[t_star - 1]).sqrt()         # :190
+        x = x0 * a[q - 1].sqrt() + noises[0] * (1.0 - a[q - 1]).sqrt()                   # :190
         y = x.view(x.shape[0], -1)
         h = 1.0 / N
         for i, k in enumerate(range(t_star - 1, -1, -1)):

@@ -7,6 +7,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+_TOOLS = os.path.join(ROOT, "tools")          # tools/synth_convnets.py: synthetic classifier containers (not product code)
+if _TOOLS not in sys.path:
+    sys.path.insert(1, _TOOLS)
 
 
 def pytest_configure(config):

@@ -21,7 +21,8 @@ warnings.filterwarnings("ignore")
 
 import models as ref_models                                            # noqa: E402  (reference package)
 from audiopure_amd import synth                                        # noqa: E402
-from audiopure_amd.audio_models.convnets import synth_init             # noqa: E402
+sys.path.insert(1, os.path.join(ROOT, "tools"))
+from synth_convnets import synth_init             # noqa: E402
 from audiopure_amd.convnet import lower                                # noqa: E402
 from oracle.convnet_plan_oracle import run_plan_torch                  # noqa: E402
 

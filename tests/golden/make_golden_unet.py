@@ -26,7 +26,8 @@ from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.unet i
 from diffusion_models.Improved_Diffusion_Unconditional.improved_diffusion.script_util import (                 # noqa: E402
     create_model, model_and_diffusion_defaults)
 from audiopure_amd import synth                                                                                # noqa: E402
-from audiopure_amd.audio_models.convnets import synth_init                                                     # noqa: E402
+sys.path.insert(1, os.path.join(ROOT, "tools"))
+from synth_convnets import synth_init                                                     # noqa: E402
 
 torch.set_grad_enabled(False)
 out = {}

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init, vgg19_bn
+from synth_convnets import CifarResNeXt, synth_init, vgg19_bn
 from audiopure_amd.convnet import lower
 from audiopure_amd import synth
 from oracle.convnet_plan_oracle import run_plan_torch

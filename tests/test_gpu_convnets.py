@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from audiopure_amd import synth
-from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init, vgg19_bn
+from synth_convnets import CifarResNeXt, synth_init, vgg19_bn
 from audiopure_amd.convnet import NativeConvNet
 from conftest import rel_err
 

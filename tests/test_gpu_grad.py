@@ -118,9 +118,9 @@ def test_white_box_gradient_through_rev_diffwave_matches_oracle(dev):
     ga, gr = xd.grad.cpu().numpy(), xr.grad.numpy()
     assert rel_err(ga, gr) < 1e-3
     assert float(np.median(np.abs(ga - gr))) < 2e-6 * float(np.abs(gr).max())
-    # forward-only calls still refuse to pretend: DiffWave.forward is no_grad in the reference (diffwave_ddpm.py:41-43)
-    with pytest.raises(NotImplementedError):
-        dw(x.to(dev).requires_grad_(True))
+    # DiffWave.forward is no_grad in the reference (diffwave_ddpm.py:41-43): a detached output, as there
+    dw.set_noise_source([z.clone() for z in zs])
+    assert not dw(x.to(dev).requires_grad_(True)).requires_grad
 
 
 def _m5_torch(sd, x, stride=16, eps=1e-5):
@@ -268,7 +268,7 @@ def test_mel_front_end_input_gradient_matches_torch_autograd(dev, L, n_mels):
 def test_convnet_input_gradient_matches_torch_autograd(dev, family):
     """NativeConvNet backward (transposed convs incl. groups and stride 2, BN folded, ReLU / residual / max- and
     avg-pool) against torch autograd through the same eval-mode module on the CPU."""
-    from audiopure_amd.audio_models.convnets import CifarResNeXt, vgg19_bn, synth_init
+    from synth_convnets import CifarResNeXt, vgg19_bn, synth_init
     from audiopure_amd.convnet import NativeConvNet
     torch.manual_seed(0)
     mod = synth_init(vgg19_bn(10) if family == "vgg19_bn" else CifarResNeXt(10), 3).eval()
@@ -299,7 +299,7 @@ def test_white_box_gradient_through_mel_and_spectrogram_classifier(dev):
     """The default route of adaptive_attack_eval.py (classifier_input mel32, --attack PGD, --defense Diffusion):
     cross_entropy(AcousticSystem(ResNeXt, mel32, RevDiffWave)(x), y).backward() entirely on the HIP path."""
     import torch.nn.functional as F
-    from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init
+    from synth_convnets import CifarResNeXt, synth_init
     from audiopure_amd.convnet import NativeConvNet
     from audiopure_amd.transforms import MelSpecDB
     from audiopure_amd.acoustic_system import AcousticSystem
@@ -363,7 +363,7 @@ class _CatSliceNet(torch.nn.Module):
 
 
 def test_convnet_backward_covers_cat_slices_and_pools(dev):
-    from audiopure_amd.audio_models.convnets import synth_init
+    from synth_convnets import synth_init
     from audiopure_amd.convnet import NativeConvNet
     mod = synth_init(_CatSliceNet(), 9).eval()
     net = NativeConvNet(mod).eval()

@@ -387,8 +387,9 @@ def test_errors_are_loud(mini, dh, dev):
     x = torch.from_numpy(synth.waveforms(1, 1000, seed=1)).to(dev)
     xg = x.clone().requires_grad_(True)
     with torch.enable_grad():
-        with pytest.raises(NotImplementedError):
-            net.eps(xg, 1.0)
+        assert net.eps(xg, 1.0).requires_grad          # an autograd node since round 2 (tests/test_gpu_dropin.py, test_gpu_grad.py)
+    with pytest.raises(ValueError):
+        net.eps(x[0], 1.0)                             # [1, L] instead of [B, 1, L]
     with pytest.raises(AssertionError):
         dw(x[0])
     with pytest.raises(TypeError):

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from audiopure_amd import synth
-from audiopure_amd.audio_models.convnets import synth_init
+from synth_convnets import synth_init
 from audiopure_amd.diffusion_models.improved_diffusion_unet import create_model, model_and_diffusion_defaults
 from audiopure_amd.diffusion_models.improved_diffusion_sde import RevImprovedDiffusion
 from conftest import rel_err
@@ -182,7 +182,7 @@ def test_white_box_loss_gradient_end_to_end_with_the_diffspec_defense(dev):
     """adaptive_attack_eval.py --defense DiffSpec --attack PGD: cross_entropy(AcousticSystem(ResNeXt, mel32,
     RevImprovedDiffusion, 'spec')(x), y).backward() on the HIP path, checked by a central difference of the native loss."""
     import torch.nn.functional as F
-    from audiopure_amd.audio_models.convnets import CifarResNeXt
+    from synth_convnets import CifarResNeXt
     from audiopure_amd.convnet import NativeConvNet
     from audiopure_amd.transforms import MelSpecDB
     from audiopure_amd.acoustic_system import AcousticSystem

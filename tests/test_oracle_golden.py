@@ -165,3 +165,31 @@ def test_melspec_matches_direct_dft():
         P = np.abs(np.fft.rfft(seg)) ** 2
         ref = 10 * np.log10(np.maximum(fb.T @ P, 1e-10))
         np.testing.assert_allclose(db[0, 0, :, fr].numpy(), ref, atol=2e-3)
+
+
+# ---- round-2 vectors (tests/golden/make_golden_v2.py): _diffusion, _reverse, fast_reverse of the reference's DiffWave ----
+@pytest.fixture(scope="module")
+def golden2():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_v2.npz"))
+
+
+def _nl(n, seed):
+    return [torch.from_numpy(synth.noise(d, 2, 16000, seed=seed)) for d in range(n)]
+
+
+def test_oracle_diffusion_and_reverse_match_reference(golden2, dh, mini):
+    cfg, w = mini
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=21))
+    xt = O.q_sample(dh, x0, 20, _nl(1, 21)[0])
+    assert rel_err(xt.numpy(), golden2["mini/diffusion_t20"]) < 1e-6
+    xr = O.ddpm_reverse(w, cfg, dh, x0 * 1.2, 4, _nl(3, 22))
+    assert rel_err(xr.numpy(), golden2["mini/reverse_n4"]) < 1e-5
+
+
+@pytest.mark.parametrize("ts", [20, 7])
+def test_oracle_fast_reverse_matches_reference(golden2, dh, mini, ts):
+    cfg, w = mini
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=21))
+    xr = O.fast_reverse(w, cfg, dh, x0 * 1.1, ts, _nl(3, 23))
+    assert rel_err(xr.numpy(), golden2[f"mini/fast_reverse_t{ts}"]) < 1e-5

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from audiopure_amd import synth
-from audiopure_amd.audio_models.convnets import synth_init
+from synth_convnets import synth_init
 from audiopure_amd.diffusion_models.improved_diffusion_unet import UNetModel, create_model, model_and_diffusion_defaults
 from audiopure_amd.diffusion_models.improved_diffusion_sde import sde_step_table
 from oracle import unet_oracle as U

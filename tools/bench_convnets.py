@@ -1,6 +1,6 @@
 import sys, time, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init, vgg19_bn
+from synth_convnets import CifarResNeXt, synth_init, vgg19_bn
 from audiopure_amd.convnet import NativeConvNet
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

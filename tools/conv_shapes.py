@@ -1,7 +1,7 @@
 import sys, os, types, torch, collections, ctypes
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from audiopure_amd import _native as N
-from audiopure_amd.audio_models.convnets import CifarResNeXt, synth_init
+from synth_convnets import CifarResNeXt, synth_init
 from audiopure_amd.convnet import NativeConvNet
 from audiopure_amd.acoustic_system import AcousticSystem
 from audiopure_amd.transforms import MelSpecDB

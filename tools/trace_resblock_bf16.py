@@ -1,4 +1,5 @@
 """Phase timeline of the bf16 residual-block kernel: per-WG cycle stamps of waves 0 and 7 (ap_debug_trace)."""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702  (-DAP_TOOLS library)
 import sys, os, ctypes as C, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audiopure_amd import synth, _native as N

@@ -1,5 +1,6 @@
 """Phase timeline of the split-precision residual-block kernels (s_memtime stamps of all 8 waves, ap_debug_trace):
 python tools/trace_resblock_f32s.py [B] [layer] [f32s|f32h]"""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702  (-DAP_TOOLS library)
 import sys, os, ctypes as C, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audiopure_amd import synth, _native as N
