@@ -10,6 +10,12 @@ workspace are resident in HBM before the timed region.  N > 1: launched by torch
 rank per GPU, utterances sharded contiguously (weak scaling: 512 per GPU), counter-based noise keyed on
 the global utterance index, one RCCL all_gather of the [B,10] log-probabilities at the end of each step.
 
+`python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself as CHILD processes
+(`python -m torch.distributed.run ... bench.py --gpus N ...`, before anything touches a GPU) and relays rank 0's line;
+`--dry-run` does the same on CPU with the gloo backend (launcher / sharding / gather plumbing only, no kernels).
+At N = 1 the same run then times the other arithmetic modes of the path (`other_modes`) and BASELINE configs[3] /
+configs[4] as their own workloads (`other_configs`), each with its own roofline object.
+
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused residual block, timed with HIP
 events on its launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on BASELINE
 config 1, timed on this node's host cores).
@@ -68,16 +74,134 @@ PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16",
                      "on the fp16 MFMA, fp32 accumulate"}
 
 
+PMC_FILES = {"f32": ["r2_pmc_traffic.json", "r1_pmc_traffic.json"], "f32s": ["r2_f32s_pmc_traffic.json", "r1_f32s_pmc_traffic.json"],
+             "f32h": ["r2_f32h_pmc_traffic.json", "r1_f32h_pmc_traffic.json"],
+             "bf16": ["r2_bf16_pmc_traffic.json", "r1_bf16_pmc_traffic.json"]}
+
+
 def pmc_traffic(B, precision="f32"):
-    """HBM-side bytes per residual-block launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 calibration, + WRITE_SIZE), scaled from the 512-clip launch it was measured on; None if absent."""
-    try:
-        name = {"f32": "r1_pmc_traffic.json", "f32s": "r1_f32s_pmc_traffic.json",
-                "f32h": "r1_f32h_pmc_traffic.json"}.get(precision, "r1_bf16_pmc_traffic.json")
-        d = json.load(open(os.path.join(ROOT, "profiles", name)))
-        return round(d["traffic_bytes_per_launch"] * B / 512.0)
-    except Exception:
-        return None
+    """HBM-side bytes per residual-block launch from the newest committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 calibration, + WRITE_SIZE), scaled from the 512-clip launch it was measured on -> (bytes or None, source).
+    The counters cannot be read from inside this process; the line says where the number comes from."""
+    for name in PMC_FILES.get(precision, []):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return round(d["traffic_bytes_per_launch"] * B / 512.0), f"profiles/{name} (separate rocprofv3 --pmc passes of this command, not measured in this run)"
+        except Exception:
+            continue
+    return None, None
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv) -> int:
+    """--gpus N > 1 outside torch.distributed.run: start the ranks as children of this (GPU-untouched) process."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args) -> None:
+    """CPU rehearsal of the multi-rank protocol (gloo): shard bounds, barrier, the scores all_gather, max-over-ranks
+    timing, one JSON line from rank 0.  No kernel runs and `value` is not a throughput."""
+    import torch
+    import torch.distributed as dist
+    from audiopure_amd.sharding import all_gather_scores, shard_bounds
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    use_dist = "RANK" in os.environ
+    if use_dist:
+        dist.init_process_group("gloo")
+    B = args.batch
+    lo, hi = shard_bounds(world * B, rank, world)
+    assert (lo, hi) == (rank * B, (rank + 1) * B)
+
+    def step():
+        lp = torch.full((B, 10), float(rank))
+        return all_gather_scores(lp, world * B) if use_dist else lp
+
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lp = step()
+    if use_dist:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert lp.shape == (world * B, 10) and all(float(lp[r * B, 0]) == r for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": f"purified 1s@16kHz utterances/sec at {args.reverse_steps} reverse steps", "dry_run": True,
+                          "value": None, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(el * 1e3 / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.precision, "data": "none (protocol rehearsal on CPU, gloo)",
+                          "config": {"workload": "dry run: launcher + sharding + scores all_gather only",
+                                     "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, logits all_gather"}}),
+              flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+UNET_GFLOP_PER_EVAL = 16.76        # shipped Improved-Diffusion UNet (52.5 M parameters) at 1 x 32 x 32, per sample (DESIGN.md 3.5)
+RESNEXT29_GFLOP = 10.77            # ResNeXt-29 8x64d at 1 x 32 x 32, per sample
+
+
+def bench_config4(dev, steps, B=256, n=5):
+    """BASELINE configs[4]: Improved-Diffusion UNet DDPM n = 5 (GaussianDiffusion q_sample + p_sample chain on mel-dB
+    spectrograms) + ResNeXt-29 classifier, batch 256, fp32 MFMA conv-as-GEMM.  Timed with HIP events on the launch
+    stream (torch's current stream is the stream every ap_* call of this path is issued on)."""
+    import torch
+    sys.path.insert(1, os.path.join(ROOT, "tools"))
+    from synth_convnets import CifarResNeXt, synth_init
+    from audiopure_amd.acoustic_system import AcousticSystem
+    from audiopure_amd.diffusion_models.improved_diffusion_ddpm import ImprovedDiffusionDDPM
+    from audiopure_amd.diffusion_models.improved_diffusion_unet import create_model, model_and_diffusion_defaults
+    from audiopure_amd.transforms import MelSpecDB
+    unet = synth_init(create_model(**model_and_diffusion_defaults()), 0).to(dev)
+    clf = synth_init(CifarResNeXt(10), 0).to(dev)                       # a plain module: AcousticSystem lowers it
+    system = AcousticSystem(classifier=clf, transform=MelSpecDB(32), defender=ImprovedDiffusionDDPM(unet, reverse_timestep=n),
+                            defense_type="spec").eval()
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    x = (torch.rand((B, 1, 16000), device=dev, generator=g) - 0.5).contiguous()
+    with torch.no_grad():
+        y = system(x, True)                                             # warm-up: lowering, weight packing
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            y = system(x, True)
+        e1.record()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    assert y.shape == (B, 10) and torch.isfinite(y).all()
+    ev_ms = e0.elapsed_time(e1) / steps
+    gflop = n * UNET_GFLOP_PER_EVAL + RESNEXT29_GFLOP
+    tf = gflop * B / (ev_ms * 1e-3) / 1e3
+    return {"workload": f"mel-dB front-end -> Improved-Diffusion UNet DDPM n={n} (ImprovedDiffusionDDPM) -> ResNeXt-29 8x64d, "
+                        f"batch={B}, fp32 MFMA conv-as-GEMM, 1 s @ 16 kHz clips",
+            "value": round(B * steps / el, 3), "unit": "utterances/s", "steps": steps, "warmup": 1,
+            "ms_per_step": round(el * 1e3 / steps, 3), "dtype": "f32",
+            "roofline": {"bound": "mfma", "kernel": "conv2d_f32_big2_kernel family (every conv / linear layer of the step)",
+                         "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "note": f"whole-step algorithmic flops ({n} x {UNET_GFLOP_PER_EVAL} + {RESNEXT29_GFLOP} GFLOP per sample) / "
+                                 "HIP-event time of the step: a lower bound of the conv kernels' own rate (GroupNorm, attention, "
+                                 "mel and the sampler updates are inside the interval)",
+                         "event_ms_per_step": round(ev_ms, 3)}}
 
 
 def main():
@@ -92,7 +216,18 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f32s", "f32h", "bf16"], default="f32",
                     help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + gather protocol; no kernels")
     args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Children, not exec: nothing in this process has touched a GPU, and it only relays the ranks' exit code.
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    if world_env != args.gpus and "RANK" in os.environ:
+        raise SystemExit(f"WORLD_SIZE={world_env} but --gpus {args.gpus}")
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     import torch.distributed as dist
@@ -107,9 +242,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP devices visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ          # under torch.distributed.run even N=1 exercises RCCL
@@ -136,14 +270,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(precision, steps, warmup):
+    def run_mode(precision, steps, warmup, sampler=None, n=n):
         """W untimed + K timed passes of the hot path in one arithmetic mode -> (elapsed s, kernel ms, launches)."""
+        sampler = sampler or args.sampler
         net.set_precision(precision)
         dw = DiffWave(model=net, diffusion_hyperparams=calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG),
                       reverse_timestep=n)
         dw.set_noise_source(("philox", 1234, rank * B))          # global utterance index = rank*B + b
         defender = dw
-        if args.sampler == "sde":                                # BASELINE configs[3]: RevDiffWave VP-SDE Euler chain
+        if sampler == "sde":                                     # BASELINE configs[3]: RevDiffWave VP-SDE Euler chain
             from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
             defender = RevDiffWave.from_model(dw, types.SimpleNamespace(
                 t=n, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1))
@@ -179,17 +314,18 @@ def main():
 
     def roofline(precision, k_ms, launches):
         achieved = FLOP_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic(B, precision)
         if precision == "f32":
             roof = {"bound": "mfma", "kernel": "resblock_f32_kernel<256,64>", "achieved": round(achieved, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": pmc_traffic(B)}
+                    "traffic": traffic}
         elif precision == "f32s":
             # fp32 operands as three bf16 parts, 6 bf16 MFMAs per fp32 MFMA-equivalent: the ceiling for ALGORITHMIC
             # flops is the dense bf16 MFMA peak / 6
             peak = 2500.0 / 6.0
             roof = {"bound": "mfma", "kernel": "resblock_f32s_kernel<256>", "achieved": round(achieved, 2),
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": pmc_traffic(B, "f32s"),
+                    "traffic": traffic,
                     "note": "algorithmic fp32 flops; each is 6 v_mfma_f32_32x32x16_bf16 partial products (exact 3-way "
                             "bf16 operand split, fp32 accumulate), so peak = 2500 TFLOP/s dense bf16 / 6",
                     "executed_bf16_TFLOPs": round(6 * achieved, 1)}
@@ -197,16 +333,16 @@ def main():
             peak = 2500.0 / 3.0                       # 3 fp16 MFMAs (same rate as bf16) per fp32 MFMA-equivalent
             roof = {"bound": "mfma", "kernel": "resblock_f32h_kernel<256>", "achieved": round(achieved, 2),
                     "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": pmc_traffic(B, "f32h"),
+                    "traffic": traffic,
                     "note": "algorithmic fp32 flops; each is 3 v_mfma_f32_32x32x16_f16 partial products (operands as two "
                             "fp16 parts, fp32 accumulate), so peak = 2500 TFLOP/s dense fp16 / 3",
                     "executed_f16_TFLOPs": round(3 * achieved, 1)}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "resblock_bf16_kernel<256>", "achieved": round(gbs, 1), "peak": 8000.0,
-                    "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic(B, "bf16"),
+                    "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic,
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
-        roof.update({"launches": launches, "avg_launch_ms": round(k_ms, 4),
+        roof.update({"traffic_source": traffic_source, "launches": launches, "avg_launch_ms": round(k_ms, 4),
                      "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,
                      "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
                      "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)})
@@ -223,11 +359,24 @@ def main():
             if prec == "f32" and args.precision != "f32":
                 e2, k2, l2 = run_mode(prec, 1, 0)
                 st = 1
-            else:
-                e2, k2, l2 = run_mode(prec, args.steps, args.warmup)
-                st = args.steps
+            else:                                  # extra evidence, not the headline: bounded so the default run stays short
+                st = max(1, min(args.steps, 3))
+                e2, k2, l2 = run_mode(prec, st, min(args.warmup, 1))
             others[prec] = {"arithmetic": PREC_NAME[prec], "value": round(B * st / e2, 3), "unit": "utterances/s",
                             "steps": st, "ms_per_step": round(e2 * 1e3 / st, 3), "roofline": roofline(prec, k2, l2)}
+
+    other_configs = {}
+    if world == 1 and not args.no_other_configs:
+        # BASELINE configs[3]: DiffWave VP-SDE reverse (diffwave_sde.py), n = 10, batch 512, bf16
+        st = max(1, min(args.steps, 2))
+        e3, k3, l3 = run_mode("bf16", st, 1, sampler="sde", n=10)
+        other_configs["configs[3]"] = {
+            "workload": f"DiffWave VP-SDE (RevDiffWave Euler chain) n=10 + M5 classify, batch={B}, bf16 MFMA operands / fp32 "
+                        "accumulate and storage, 1 s @ 16 kHz clips",
+            "value": round(B * st / e3, 3), "unit": "utterances/s", "steps": st, "warmup": 1,
+            "ms_per_step": round(e3 * 1e3 / st, 3), "dtype": "bf16", "roofline": roofline("bf16", k3, l3)}
+        net.set_precision(args.precision)
+        other_configs["configs[4]"] = bench_config4(dev, max(1, min(args.steps, 5)))
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -247,6 +396,8 @@ def main():
         }
         if others:
             out["other_modes"] = others
+        if other_configs:
+            out["other_configs"] = other_configs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -115,7 +115,7 @@ def test_script_built_mel_compose_and_plain_convnet_run_natively(dev):
     with torch.no_grad():
         ref = clf(mel)                                              # torch module on the SAME native mel: classifier parity
     assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 1e-3
-    assert torch.equal(got, NativeConvNet(clf, (1, 32, 32))(mel))   # lazily traced plan == explicitly traced plan
+    assert torch.equal(got, NativeConvNet(clf, (1, 32, 32)).eval()(mel))   # lazily traced plan == explicitly traced plan
 
 
 # ---- 2. surface that had no test: _diffusion, _reverse (noise list), fast_reverse -----------------------------------------

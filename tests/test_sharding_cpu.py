@@ -55,3 +55,21 @@ def test_world2_gather_equals_single_process(tmp_path, n_total):
 def test_single_process_passthrough():
     x = torch.arange(12.0).view(4, 3)
     assert all_gather_scores(x, 4) is x
+
+
+def test_bench_self_launches_its_ranks_as_children_and_prints_one_line():
+    """`python bench.py --gpus 2 --dry-run` (the driver's command form, no torchrun around it): the launcher starts two
+    gloo ranks as child processes and rank 0 prints exactly one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1",
+                        "--batch", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
