@@ -844,7 +844,11 @@ extern "C" int ap_debug_force_f32(int on) {
   return 0;
 }
 
-namespace ap { extern int g_ablate_bf16; extern unsigned long long *g_trace_bf16; }
+namespace ap { extern int g_ablate_bf16; extern int g_dbg_bf16; extern unsigned long long *g_trace_bf16; }
+extern "C" int ap_debug_bf16_dbg(int bits) {
+  ap::g_dbg_bf16 = bits;
+  return 0;
+}
 
 // timing-only: device buffer (nblk x 2 x 16 u64) the bf16 residual block writes phase timestamps into; null = off
 extern "C" int ap_debug_trace(void *buf) {

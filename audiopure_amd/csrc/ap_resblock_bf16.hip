@@ -242,6 +242,29 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     }
   };
 
+  // X4 staging split into 8 pieces (sample i, channel-pair half hf) so that it can be placed between the MFMAs of the
+  // chunk's second half instead of after them: 4 adds + 2 cvt_pk + 2 and per piece, the ds_write_b128 after a
+  // sample's second piece.
+  float ptv8[8];
+  u32x4 pkq;
+  auto pack_ptv = [&](int ch) {
+    const float4 p0 = *reinterpret_cast<const float4 *>(ptx + ch * BKC);
+    const float4 p1 = *reinterpret_cast<const float4 *>(ptx + ch * BKC + 4);
+    ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
+    ptv8[4] = p1.x; ptv8[5] = p1.y; ptv8[6] = p1.z; ptv8[7] = p1.w;
+  };
+  auto pack_piece = [&](unsigned char *dst, auto i_tag, auto hf_tag) {
+    constexpr int i = decltype(i_tag)::value, hf = decltype(hf_tag)::value;
+    if constexpr (DBG & 4) return;                             // timing-only: no pack
+    const unsigned keep = tok[0] ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int e2 = 2 * hf; e2 < 2 * hf + 2; e2++)
+      pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                                                 f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
+                                                       xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep;
+    if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XSTRIDE + xk) * 2) = pkq;
+  };
+
   issue_loads(0);
   __syncthreads();                                              // part_t visible
   store_chunk(lds, 0);
@@ -264,13 +287,20 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     for (int s = 0; s < 3; s++) {
       bf16x8 bv[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++)
-        bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * rowbytes + s * 32);
+      for (int ct = 0; ct < 4; ct++) {
+        if constexpr (DBG & 16) asm volatile("" : "=v"(bv[ct]));
+        else bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * rowbytes + s * 32);
+      }
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-          acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][rt], bv[ct], acc[rt][ct], 0, 0, 0);
+        for (int ct = 0; ct < 4; ct++) {
+          if constexpr (DBG & 8) {
+            asm volatile("" :: "v"(a[s][rt]), "v"(bv[ct]));
+          } else {
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][rt], bv[ct], acc[rt][ct], 0, 0, 0);
+          }
+        }
     }
   };
 
@@ -316,6 +346,68 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  // X4: the light half in explicit order -- one filler group per MFMA, pinned with sched_barrier(0): next set's weight
+  // fragments first (6 loads), the B fragments one k-step ahead, then the eight pack pieces of the next chunk.
+  auto half_light_packed = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], const u32x4 *nsrc,
+                               unsigned char *pdst, int pch) {
+    bf16x8 bva[4], bvb[4];
+    auto rdb = [&](bf16x8(&bv)[4], int s2) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        if constexpr (DBG & 16) asm volatile("" : "=v"(bv[ct]));
+        else bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (XSTRIDE * 2) + s2 * 32);
+      }
+    };
+    rdb(bva, 0);
+    pack_ptv(pch);
+    __builtin_amdgcn_sched_barrier(0);
+    auto mf = [&](const bf16x8 &a, const bf16x8 &b, int rt, int ct) {
+      if constexpr (DBG & 8) {                                 // timing-only: no MFMA (operands kept alive)
+        asm volatile("" :: "v"(a), "v"(b));
+      } else {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[rt][ct], 0, 0, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    // k-step 0 (gaps 0-7): weight loads of the next set, B fragments of k-step 1
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      mf(use[0][m >> 2], bva[m & 3], m >> 2, m & 3);
+      if (m < 6) {
+        if constexpr (!(DBG & 1)) nxt[m >> 1][m & 1] = __builtin_bit_cast(bf16x8, nsrc[m * 64]);
+      }
+      if (m >= 2 && m < 6) {
+        if constexpr (DBG & 16) asm volatile("" : "=v"(bvb[m - 2]));
+        else bvb[m - 2] = *reinterpret_cast<const bf16x8 *>(xb + (32 * (m - 2)) * (XSTRIDE * 2) + 1 * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // k-step 1 (gaps 8-15): B fragments of k-step 2, pack pieces 0-3
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      mf(use[1][m >> 2], bvb[m & 3], m >> 2, m & 3);
+      if (m == 1) pack_piece(pdst, I0{}, I0{});
+      if (m == 3) pack_piece(pdst, I0{}, I1{});
+      if (m == 5) pack_piece(pdst, I1{}, I0{});
+      if (m == 7) pack_piece(pdst, I1{}, I1{});
+      if (m >= 4) {
+        if constexpr (DBG & 16) asm volatile("" : "=v"(bva[m - 4]));
+        else bva[m - 4] = *reinterpret_cast<const bf16x8 *>(xb + (32 * (m - 4)) * (XSTRIDE * 2) + 2 * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // k-step 2 (gaps 16-23): pack pieces 4-7
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      mf(use[2][m >> 2], bva[m & 3], m >> 2, m & 3);
+      if (m == 0) pack_piece(pdst, I2{}, I0{});
+      if (m == 2) pack_piece(pdst, I2{}, I1{});
+      if (m == 4) pack_piece(pdst, I3{}, I0{});
+      if (m == 6) pack_piece(pdst, I3{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto set0 = [&](int ch) { return ap + (size_t)(ch * 6) * 128; };
   auto set1 = [&](int ch) { return ap + (size_t)(ch * 6 + 3) * 128; };
   if (!STAGGER || wave < NW / 2) {
@@ -327,9 +419,14 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
       const unsigned char *xb = xbuf(ch) + rdoff;
       half_heavy(a0, xb, a1, set1(ch), nx);
       if (ch == 4) mark(10);
-      half_light(a1, xb + 3 * 32, a0, set0(nx));
-      if (ch == 4) mark(11);
-      store_chunk(xbuf(ch + 1), nx);
+      if constexpr (X4 && !STAGGER) {
+        half_light_packed(a1, xb + 3 * 32, a0, set0(nx), xbuf(ch + 1), nx);
+        if (ch == 4) mark(11);
+      } else {
+        half_light(a1, xb + 3 * 32, a0, set0(nx));
+        if (ch == 4) mark(11);
+        store_chunk(xbuf(ch + 1), nx);
+      }
       if (ch == 4) mark(12);
       __syncthreads();
       if (ch == 0) mark(2);
@@ -374,7 +471,9 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   auto load_a4 = [&](bf16x8(&a)[4], int gks) {                   // gks = k-step over both passes, clamped to the last set
     const u32x4 *base = ap2 + (size_t)(gks <= 2 * NKS - 4 ? gks : 2 * NKS - 4) * 64;
 #pragma unroll
-    for (int s = 0; s < 4; s++) a[s] = __builtin_bit_cast(bf16x8, base[s * 64]);
+    for (int s = 0; s < 4; s++) {
+      if constexpr (!(DBG & 1024)) a[s] = __builtin_bit_cast(bf16x8, base[s * 64]);                  // timing-only: no W2 loads
+    }
   };
   float4 bias[4];
   auto fetch_bias = [&](auto pass_tag) {
@@ -402,8 +501,10 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
     for (int qq = 0; qq < 4; qq++) {
       bf16x4 pk;
 #pragma unroll
-      for (int e = 0; e < 4; e++)
-        pk[e] = (__bf16)gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
+      for (int e = 0; e < 4; e++) {
+        if constexpr (DBG & 32) pk[e] = (__bf16)(acc[0][ct][4 * qq + e] + acc[1][ct][4 * qq + e]);   // timing-only: no gate math
+        else pk[e] = (__bf16)gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
+      }
       *reinterpret_cast<bf16x4 *>(lds + GOFF + ((32 * ct + j) * GSTRIDE + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -436,7 +537,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   auto gemm2_pass = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
     float pre[4][16];
-    if ((pass == 0 || accumulate) && !(ablate & 1)) {
+    if ((pass == 0 || accumulate) && !(ablate & 1) && !(DBG & 128)) {
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) {
         if constexpr (E4) {
@@ -472,11 +573,15 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
       for (int s = 0; s < 4; s++) {
         bf16x8 bv[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-          bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (GSTRIDE * 2) + s * 32);
+        for (int ct = 0; ct < 4; ct++) {
+          if constexpr (DBG & 2048) asm volatile("" : "=v"(bv[ct]));                                 // timing-only: no g reads
+          else bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (GSTRIDE * 2) + s * 32);
+        }
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-          ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv[ct], ac[ct], 0, 0, 0);
+        for (int ct = 0; ct < 4; ct++) {
+          if constexpr (DBG & 64) asm volatile("" :: "v"(a[s]), "v"(bv[ct]));                      // timing-only: no GEMM2 MFMA
+          else ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv[ct], ac[ct], 0, 0, 0);
+        }
       }
     };
 #pragma unroll 1
@@ -502,10 +607,14 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
       for (int ct = 0; ct < 4; ct++) {
         if constexpr (E4) {
 #pragma unroll
-          for (int r = 0; r < 16; r++) patch[rowoff_b(r, hh) * PSTR + j] = ac[ct][r];
+          for (int r = 0; r < 16; r++) {
+            if constexpr (!(DBG & 512)) patch[rowoff_b(r, hh) * PSTR + j] = ac[ct][r];
+          }
 #pragma unroll
           for (int p = 0; p < 4; p++) {
-            const float4 v = *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * p) * PSTR + 4 * (lane & 7));
+            float4 v;
+            if constexpr (DBG & 512) { v.x = ac[ct][4 * p]; v.y = ac[ct][4 * p + 1]; v.z = ac[ct][4 * p + 2]; v.w = ac[ct][4 * p + 3]; }   // timing-only: no LDS transpose
+            else v = *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * p) * PSTR + 4 * (lane & 7));
             f32x4 o;
             o[0] = ((add ? pre[ct][4 * p + 0] : 0.f) + v.x) * scale;
             o[1] = ((add ? pre[ct][4 * p + 1] : 0.f) + v.y) * scale;
@@ -513,8 +622,9 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
             o[3] = ((add ? pre[ct][4 * p + 3] : 0.f) + v.w) * scale;
             // row step in the VGPR offset, soffset = 0: a >8-byte buffer store with an SGPR soffset reads its data
             // late, and the compiler here does not guard the next write of those VGPRs (observed: torn y lanes)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), pass == 0 ? ors : srs,
-                                                   evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0);
+            if constexpr (DBG & 256) asm volatile("" :: "v"(o));                                     // timing-only: no stores
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), pass == 0 ? ors : srs,
+                                                        evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0);
           }
         } else {
 #pragma unroll
@@ -534,6 +644,8 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 }
 
 #ifdef AP_TOOLS
+int g_dbg_bf16 = 0;                           // ap_debug_bf16_dbg: timing-only template variants (bit 1 no weight loads,
+                                              // 2 no X loads, 4 no pack, 8 no MFMA, 16 no B-fragment LDS reads in GEMM1)
 int g_ablate_bf16 = 0;
 unsigned long long *g_trace_bf16 = nullptr;   // ap_debug_trace: device buffer of nblk x 2 x 16 timestamps, or null
 #endif
@@ -544,6 +656,13 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
   if (C != 256) {
     set_error("AP_PREC_BF16 is built for res_channels = 256 only (got %d)", C);
     return -22;
+  }
+#ifdef AP_TOOLS
+  if (!(g_dbg_bf16 & 0x1000) && !g_trace_bf16)                  // 0x1000: force the per-tile kernel below (A/B timing)
+#endif
+  {
+    const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);   // persistent form
+    if (rc != 1) return rc;                                      // 1: shape not served there (d % 4, L % 4) -> per-tile kernel
   }
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const int ntiles = (L + BT - 1) / BT;
@@ -559,7 +678,18 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
                                                                         AP_ABLATE_ARG(g_ablate_bf16), AP_TRACE_BUF)
 #ifdef AP_TOOLS
 #define AP_TRACE_BUF g_trace_bf16
-  if (g_trace_bf16 && x4) {
+  if (!g_trace_bf16 && x4 && (g_dbg_bf16 & 0xfff)) {
+#define AP_DBG_CASE(D) case D: resblock_bf16_kernel<256, true, true, false, D><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, nullptr); break;
+    switch (g_dbg_bf16 & 0xfff) {
+      AP_DBG_CASE(1) AP_DBG_CASE(2) AP_DBG_CASE(3) AP_DBG_CASE(4) AP_DBG_CASE(7) AP_DBG_CASE(8) AP_DBG_CASE(16) AP_DBG_CASE(23) AP_DBG_CASE(31)
+      AP_DBG_CASE(31 + 32) AP_DBG_CASE(31 + 64) AP_DBG_CASE(31 + 128) AP_DBG_CASE(31 + 256) AP_DBG_CASE(31 + 384) AP_DBG_CASE(31 + 512)
+      AP_DBG_CASE(31 + 1024) AP_DBG_CASE(31 + 2048) AP_DBG_CASE(31 + 64 + 1024 + 2048) AP_DBG_CASE(31 + 384 + 512)
+      AP_DBG_CASE(31 + 32 + 384 + 512) AP_DBG_CASE(4095)
+      default: set_error("no such DBG instantiation"); return -22;
+    }
+#undef AP_DBG_CASE
+  }
+  else if (g_trace_bf16 && x4) {
     switch ((g_ablate_bf16 >> 6) & 3) {
       case 1: resblock_bf16_kernel<256, true, true, true, 1><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, g_trace_bf16); break;
       case 2: resblock_bf16_kernel<256, true, true, true, 2><<<(unsigned)nblk, 512, 0, st>>>(hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, ntiles, nblk, g_ablate_bf16, g_trace_bf16); break;

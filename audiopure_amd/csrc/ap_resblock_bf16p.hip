@@ -1,0 +1,618 @@
+// AP_PREC_BF16, persistent form: fused Residual_block.forward (WaveNet.py:75-97) with bf16 MFMA operands, fp32 accumulate,
+// fp32 activations in HBM -- the same arithmetic and the same packed weight images as ap_resblock_bf16.hip, restructured
+// around what the round-2 ablations measured (tools/dbg_resblock_bf16.py):
+//
+//   * with GEMM1 emptied the old kernel still took 52 % of its time, and 60 % of THAT was the residual / skip
+//     read-modify-write traffic (262 KB of loads + 262 KB of stores per 128-sample tile) issued in two bursts at the very
+//     end of a workgroup's life: every CU alternated between a phase that used no memory bandwidth and a phase that used
+//     nothing else, then paid a store drain (s_endpgm waits for vmcnt = 0), a workgroup launch and a cold first load.
+//
+// Here one workgroup per CU walks its tiles in a loop (XCD-local order), and the memory traffic of a tile is spread over
+// the tile and into the next one:
+//   - the h patch the residual needs is requested during GEMM1's last chunk (the staging registers are free by then), the
+//     running skip rows during the gate (the GEMM1 accumulators free up as they are gated);
+//   - the first X chunk of the NEXT tile is requested before the last epilogue's stores, so the stores of a tile drain
+//     behind the next tile's GEMM1 and no wait ever names them (vmcnt retires in order: a load issued after a store could
+//     not be waited for without waiting for the store);
+//   - the next chunk's FiLM add / bf16 pack / ds_write sit between the MFMAs of a chunk's second half (two X buffers
+//     instead of three), so the chunk has no VALU-only tail.
+// Layout notes: X image [column][k] bf16, 208-B rows (conflict-free ds_read_b128 B fragments); g image [column][channel],
+// 528-B rows; wave-private 32 x 32 fp32 output patch with 128-B rows (with the 16-lane groups of ds_read_b128 a padded
+// 144-B row was 2-way conflicted, the unpadded one is conflict-free for both the column writes and the row reads).
+#include <type_traits>
+
+#include "ap_common.h"
+
+namespace ap {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PT_ = 128;                 // time tile
+constexpr int KC_ = 32;                  // channels per staged chunk -> 96 K rows = 6 k-steps of 16
+constexpr int XS_ = 3 * KC_ + 8;         // bf16 per column row of the X image (208 B)
+constexpr int GS_ = 256 + 8;             // bf16 per column row of the g image (528 B)
+constexpr int PS_ = 32;                  // fp32 per row of the wave-private output patch (128 B)
+
+__device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// tanh(a) sigmoid(b) with E = e^(-2|a|) in (0,1], F = e^(-b) (may overflow to +inf -> gate 0, the limit); no clamps
+__device__ __forceinline__ float gate_fast(float a, float b) {
+  const float E = __builtin_amdgcn_exp2f(__builtin_fabsf(a) * -2.885390081777926815f);
+  const float F = __builtin_amdgcn_exp2f(b * -1.442695040888963407f);
+  const float g = (1.0f - E) * __builtin_amdgcn_rcpf((1.0f + E) * (1.0f + F));
+  return __builtin_copysignf(g, a);
+}
+
+using I0 = std::integral_constant<int, 0>;
+using I1 = std::integral_constant<int, 1>;
+using I2 = std::integral_constant<int, 2>;
+using I3 = std::integral_constant<int, 3>;
+
+}  // namespace
+
+// DBG (tools builds only; outputs wrong by construction): 1 no weight loads in GEMM1's loop, 2 no X loads, 4 no pack,
+// 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
+// 256 no stores, 512 no L2 prefetch.
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
+    const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
+    const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
+    const void *__restrict__ bbase, unsigned bbytes, unsigned b1_off, unsigned b2_off,        // fp32 bias vectors (one slab)
+    int L, int d, int accumulate, int ntiles, int nblk) {
+  constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
+  constexpr int XBYTES = PT_ * XS_ * 2;                         // 26,624 B per X buffer, two buffers
+  constexpr int GOFF = 2 * XBYTES;
+  constexpr int POFF = GOFF + PT_ * GS_ * 2;                   // output patches: 8 waves x 32 x 32 fp32
+  constexpr int PTOFF = POFF + NW * 32 * PS_ * 4;              // part_t (C floats)
+  constexpr int LDS_BYTES = PTOFF + C * 4;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+
+  // ---- tile walk: workgroups g, g+8, g+16, ... share an XCD (round-robin dispatch); each XCD takes a contiguous run of
+  // (clip, tile) work and its workgroups interleave inside that run, so at any moment the CUs of an XCD hold neighbouring
+  // tiles of one clip and the +-d taps / the residual patch are re-read from that XCD's L2.  Placement only affects speed.
+  int t_first, t_step, t_end;
+  {
+    const int g = blockIdx.x, G = gridDim.x;
+    if (G >= 8 && (G & 7) == 0) {
+      const int xcd = g & 7, idx = g >> 3, q = nblk >> 3, r = nblk & 7;
+      const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      t_first = base + idx;
+      t_step = G >> 3;
+      t_end = base + q + (xcd < r ? 1 : 0);
+    } else {
+      t_first = g;
+      t_step = G;
+      t_end = nblk;
+    }
+  }
+  if (t_first >= t_end) return;
+
+  const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
+  auto clip_rsrc = [&](const float *base, int b) {
+    const uint64_t hb = (uint64_t)(base + (size_t)b * C * L);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)clip_bytes, 0x00020000);
+  };
+
+  // ---- X staging geometry (fixed per thread): (tap = wave/2, column quad cg, channel octet oct); lane bits (low to high)
+  // cg&3, oct, cg>>2 so a load covers whole 64-B runs per channel row.  Waves 6, 7 repeat tap 2.
+  const int xtap = min(wave >> 1, 2);
+  const int cg = ((wave & 1) * 4 + (lane >> 4)) * 4 + (lane & 3), oct = (lane >> 2) & 3;
+  const int xcol = 4 * cg, xk = xtap * KC_ + oct * 8;
+  const float *ptx = reinterpret_cast<const float *>(lds + PTOFF) + oct * 8;
+
+  if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
+
+  float xr[32];
+  auto tile_bt = [&](int tile, int &b, int &t0) {
+    b = __builtin_amdgcn_readfirstlane(tile / ntiles);
+    t0 = __builtin_amdgcn_readfirstlane((tile % ntiles) * PT_);
+  };
+  auto x_geom = [&](int t0, unsigned &voff, bool &tok) {
+    const int tp = t0 + 4 * cg + (xtap - 1) * d;
+    tok = (tp >= 0) && (tp < L);
+    voff = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+  };
+  const __amdgpu_buffer_rsrc_t hrs_clip0 = clip_rsrc(hin, 0);
+  auto issue_x = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch) {
+    if constexpr (DBG & 2) return;
+    const __amdgpu_buffer_rsrc_t &rs = (DBG & 1024) ? hrs_clip0 : rs_in;      // timing-only: every tile stages clip 0 (cache-resident X)
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      // (bit_cast the whole vector: element-wise bit_cast of the builtin's int vector is mis-folded to a splat)
+      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (ch * KC_ + e) * L * 4, 0));
+#pragma unroll
+      for (int i = 0; i < 4; i++) xr[e * 4 + i] = v[i];
+    }
+  };
+  // ---- software prefetch into L2: one dword per 128-B line, two chunks (and the read-modify-write operands a few
+  // microseconds) ahead of the wide loads that use the data.  A wide load issued one chunk ahead of its use does not
+  // cover an HBM miss under load (the ablation without X loads was 26 % faster), and deeper register staging does not fit;
+  // the sparse loads cost one VGPR and ~1 instruction per wave and chunk, and turn the later loads into L2 hits.
+  const int pf_tap = tid >> 7, pf_c = (tid & 127) >> 2, pf_ln = tid & 3;    // threads 0..383: (tap, channel, line of the row)
+  auto prefetch_x = [&](const __amdgpu_buffer_rsrc_t &rs, int t0p, int ch) -> unsigned {
+    if constexpr (!(DBG & 2048)) return 0u;
+    unsigned v = 0;
+    if (tid < 384) {                                            // waves 6, 7 sit out (wave-uniform)
+      const int tp = min(max(t0p + (pf_tap - 1) * d + pf_ln * 32, 0), L - 1);
+      v = __builtin_amdgcn_raw_buffer_load_b32(rs, ((unsigned)(ch * KC_ + pf_c) * (unsigned)L + (unsigned)tp) * 4u, 0, 0);
+    }
+    return v;
+  };
+  auto prefetch_rows = [&](const __amdgpu_buffer_rsrc_t &rs, int t0p, int half) -> unsigned {   // 256 rows x 4 lines, 2 halves
+    if constexpr (!(DBG & 2048)) return 0u;
+    const int row = half * 128 + (tid >> 2), tp = min(t0p + (tid & 3) * 32, L - 1);
+    return __builtin_amdgcn_raw_buffer_load_b32(rs, ((unsigned)row * (unsigned)L + (unsigned)tp) * 4u, 0, 0);
+  };
+  float ptv8[8];
+  u32x4 pkq;
+  auto pack_ptv = [&](int ch) {
+    const float4 p0 = *reinterpret_cast<const float4 *>(ptx + ch * KC_);
+    const float4 p1 = *reinterpret_cast<const float4 *>(ptx + ch * KC_ + 4);
+    ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
+    ptv8[4] = p1.x; ptv8[5] = p1.y; ptv8[6] = p1.z; ptv8[7] = p1.w;
+  };
+  // one eighth of a chunk's staging: sample i, channel pairs 2hf, 2hf+1 -> 4 adds, 2 cvt_pk, 2 and; the ds_write_b128 follows
+  // a sample's second piece.  FiLM add (WaveNet.py:84), zero padding (:26-27) as an AND with the in-range mask.
+  auto pack_piece = [&](unsigned char *dst, unsigned keep, auto i_tag, auto hf_tag) {
+    constexpr int i = decltype(i_tag)::value, hf = decltype(hf_tag)::value;
+    if constexpr (DBG & 4) return;
+#pragma unroll
+    for (int e2 = 2 * hf; e2 < 2 * hf + 2; e2++)
+      pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                                                 f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
+                                                       xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep;
+    if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS_ + xk) * 2) = pkq;
+  };
+  auto pack_all = [&](unsigned char *dst, unsigned keep, int ch) {
+    pack_ptv(ch);
+    pack_piece(dst, keep, I0{}, I0{}); pack_piece(dst, keep, I0{}, I1{});
+    pack_piece(dst, keep, I1{}, I0{}); pack_piece(dst, keep, I1{}, I1{});
+    pack_piece(dst, keep, I2{}, I0{}); pack_piece(dst, keep, I2{}, I1{});
+    pack_piece(dst, keep, I3{}, I0{}); pack_piece(dst, keep, I3{}, I1{});
+  };
+
+  // ---- weight fragment streams (this wave's 64 GEMM1 rows / 2 x 32 GEMM2 rows), L2 -> registers.  Buffer loads with the
+  // fragment index in the scalar offset: one VGPR (lane * 16) addresses every fragment (64-bit per-lane pointers, one pair
+  // per fragment slot, were hoisted out of the tile loop by the compiler and spilled).
+  auto uni_rsrc = [&](const void *base, unsigned bytes) {
+    const uint64_t hb = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t wrs = uni_rsrc(wbase, wbytes);
+  const __amdgpu_buffer_rsrc_t brs = uni_rsrc(bbase, bbytes);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // GEMM1 image [wave][chunk][kstep 6][rowtile 2][lane][8 bf16]: fragment f of this wave = f KB from the wave's base
+  auto ld_w1 = [&](int frag) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, w1_off + (wave * NCH * 12 + frag) * 1024, 0));
+  };
+  // GEMM2 image [wave][rowtile 2][kstep 16][lane][8 bf16]; gks runs over pass 0's then pass 1's k-steps
+  auto ld_w2 = [&](int gks) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, w2_off + (wave * 2 * NKS + gks) * 1024, 0));
+  };
+  const int rdoff = (j * XS_ + 8 * hh) * 2;                     // this lane's B-fragment byte offset inside an X buffer
+  const unsigned char *gb = lds + GOFF + (j * GS_ + 8 * hh) * 2;
+  float *patch = reinterpret_cast<float *>(lds + POFF) + wave * 32 * PS_;
+  const float RS = 0.707106781186547524f;
+
+  // ---- first tile: parameters and chunk-0 request
+  int b_cur, t0_cur;
+  tile_bt(t_first, b_cur, t0_cur);
+  __amdgpu_buffer_rsrc_t hrs = clip_rsrc(hin, b_cur);
+  unsigned xvoff;
+  bool xtok;
+  x_geom(t0_cur, xvoff, xtok);
+  issue_x(hrs, xvoff, 0);
+  __syncthreads();                                               // part_t visible
+
+#pragma unroll 1
+  for (int tile = t_first; tile < t_end; tile += t_step) {
+    const unsigned keep = xtok ? 0xffffffffu : 0u;
+    const int t0 = t0_cur;
+    const int ntile = tile + t_step;
+    // the bias vectors are re-fetched per tile (L2 / scalar-cache hits): hoisted out of the tile loop they would occupy 64
+    // registers for the whole kernel and spill -- the empty asm makes the pointers opaque per iteration
+    unsigned bias_tok = 0;
+    asm volatile("" : "+s"(bias_tok));
+    // ================================================ GEMM1 =========================================================
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const f32x4 bv4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)hh * 16u, b1_off + (rt * C + 32 * wave + 8 * q) * 4 + bias_tok, 0));
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+          acc[rt][ct][4 * q + 0] = bv4[0];
+          acc[rt][ct][4 * q + 1] = bv4[1];
+          acc[rt][ct][4 * q + 2] = bv4[2];
+          acc[rt][ct][4 * q + 3] = bv4[3];
+        }
+      }
+    bf16x8 a0[3][2], a1[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++) a0[s][rt] = ld_w1(s * 2 + rt);
+    pack_all(lds, keep, 0);                                      // chunk 0 was requested during the previous tile
+    __syncthreads();
+
+    auto mf = [&](const bf16x8 &a, const bf16x8 &bq, int rt, int ct) {
+      if constexpr (DBG & 8) {
+        asm volatile("" ::"v"(a), "v"(bq));
+      } else {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[rt][ct], 0, 0, 0);
+      }
+    };
+    auto rdb = [&](bf16x8 &dst, const unsigned char *xb, int ct, int s) {
+      if constexpr (DBG & 16) asm volatile("" : "=v"(dst));
+      else dst = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (XS_ * 2) + s * 32);
+    };
+    // heavy half: k-steps 0-2 of the chunk on fragment set `use`; requests set `nxt` (6 loads) and the next chunk's X rows
+    // (8 loads), one between each of the first MFMAs (the CU's memory pipe takes a wave-wide load every ~16 cycles)
+    auto half_heavy = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], int nfrag, int xch,
+                          bool with_x) {
+      if constexpr (!(DBG & 1)) {
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+#pragma unroll
+          for (int rt = 0; rt < 2; rt++) nxt[s][rt] = ld_w1(nfrag + s * 2 + rt);
+      }
+      if (with_x) issue_x(hrs, xvoff, xch);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+        bf16x8 bv[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xb, ct, s);
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+          for (int ct = 0; ct < 4; ct++) mf(use[s][rt], bv[ct], rt, ct);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int i = 0; i < 24; i++) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if ((i & 7) >= 3 && (i & 7) <= 6 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // light half: k-steps 3-5 in explicit order; fillers = the next set's weight fragments, the B fragments one k-step
+    // ahead, then (PACK) the eight staging pieces of the next chunk or (PRE) the 16 loads of the residual's h patch
+    float pre[4][16];
+    unsigned evoff[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ct++) {                            // E4 mapping: lane = (row lane>>3 (+8 per step), column quad lane&7)
+      const int t = t0 + 32 * ct + 4 * (lane & 7);
+      evoff[ct] = t < L ? ((unsigned)(32 * wave + (lane >> 3)) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
+    }                                                           // 0x80000000: outside the clip -> loads 0, store dropped
+    auto load_pre = [&](const __amdgpu_buffer_rsrc_t &rs, auto ct_tag) {
+      constexpr int ct = decltype(ct_tag)::value;
+      if constexpr (DBG & 128) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) pre[ct][r] = 0.f;
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, evoff[ct], 8 * p * L * 4, 0));
+#pragma unroll
+          for (int i = 0; i < 4; i++) pre[ct][4 * p + i] = v[i];
+        }
+      }
+    };
+    // light half, explicit order (pinned with sched_barrier): column-tile-major MFMA pairs share one B fragment, which is
+    // re-read for the next k-step right after its pair (6 MFMAs = its latency ahead of the next use).  Fillers: the next
+    // set's six weight fragments in k-step 0, then the eight staging pieces of the next chunk.
+    auto half_light = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], int nfrag,
+                          unsigned char *pdst, int pch, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
+      bf16x8 bv[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xb, ct, 0);
+      if constexpr (!LAST) pack_ptv(pch);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 3; s++) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+          mf(use[s][0], bv[ct], 0, ct);
+          if constexpr (!LAST) {
+            if (s == 0 && !(DBG & 1)) nxt[ct >> 1][ct & 1] = ld_w1(nfrag + ct);
+            if (s == 1 && ct == 0) pack_piece(pdst, keep, I0{}, I0{});
+            if (s == 1 && ct == 1) pack_piece(pdst, keep, I1{}, I0{});
+            if (s == 1 && ct == 2) pack_piece(pdst, keep, I2{}, I0{});
+            if (s == 1 && ct == 3) pack_piece(pdst, keep, I3{}, I0{});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mf(use[s][1], bv[ct], 1, ct);
+          if (s < 2) rdb(bv[ct], xb, ct, s + 1);
+          if constexpr (!LAST) {
+            if (s == 0 && ct < 2 && !(DBG & 1)) nxt[2][ct] = ld_w1(nfrag + 4 + ct);
+            if (s == 1 && ct == 0) pack_piece(pdst, keep, I0{}, I1{});
+            if (s == 1 && ct == 1) pack_piece(pdst, keep, I1{}, I1{});
+            if (s == 1 && ct == 2) pack_piece(pdst, keep, I2{}, I1{});
+            if (s == 1 && ct == 3) pack_piece(pdst, keep, I3{}, I1{});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH - 1; ch++) {
+      const unsigned char *xb = lds + (ch & 1) * XBYTES + rdoff;
+      half_heavy(a0, xb, a1, ch * 12 + 6, ch + 1, true);
+      half_light(a1, xb + 3 * 32, a0, (ch + 1) * 12, lds + ((ch + 1) & 1) * XBYTES, ch + 1, std::false_type{});
+      if constexpr (!(DBG & 512)) __syncthreads();              // DBG 512 (timing only): no per-chunk barrier
+    }
+    {
+      const unsigned char *xb = lds + ((NCH - 1) & 1) * XBYTES + rdoff;
+      half_heavy(a0, xb, a1, (NCH - 1) * 12 + 6, 0, false);
+      half_light(a1, xb + 3 * 32, a0, 0, nullptr, 0, std::true_type{});
+    }
+
+    // ================================================ gate ==========================================================
+    // GEMM2's first requests go out ahead of the gate: the CU's memory pipe serves in order and vmcnt retires in order.
+    bf16x8 p0[4], p1[4];
+    auto load_a4 = [&](bf16x8(&a)[4], int gks) {                 // gks = k-step over both passes, clamped to the last set
+      const int g0 = gks <= 2 * NKS - 4 ? gks : 2 * NKS - 4;
+#pragma unroll
+      for (int s = 0; s < 4; s++) a[s] = ld_w2(g0 + s);
+    };
+    float4 bias[4];
+    auto fetch_bias = [&](auto pass_tag) {
+      constexpr int pass = decltype(pass_tag)::value;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int c = 32 * wave + 8 * q + 4 * hh;
+        const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)hh * 16u, b2_off + (pass * C + 32 * wave + 8 * q) * 4 + bias_tok, 0));
+        float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        if (pass == 0) {                                         // u = h + part_t re-enters the residual (alias semantics)
+          const float4 pv = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lds + PTOFF) + c);
+          v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+        }
+        bias[q] = v;
+      }
+    };
+    load_a4(p0, 0);
+    load_pre(hrs, I0{});                                         // the residual's h patch, first half (what fits beside the accumulators)
+    load_pre(hrs, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+
+    const __amdgpu_buffer_rsrc_t srs = clip_rsrc(skip, b_cur);
+    const __amdgpu_buffer_rsrc_t ors = clip_rsrc(hout, b_cur);
+    float pre1[4][16];                                           // the running skip rows pass 1 adds into
+    auto load_pre1 = [&](auto ct_tag) {
+      constexpr int ct = decltype(ct_tag)::value;
+      if ((DBG & 128) || !accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) pre1[ct][r] = 0.f;
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, evoff[ct], 8 * p * L * 4, 0));
+#pragma unroll
+          for (int i = 0; i < 4; i++) pre1[ct][4 * p + i] = v[i];
+        }
+      }
+    };
+    auto gate_ct = [&](auto ct_tag) {
+      constexpr int ct = decltype(ct_tag)::value;
+#pragma unroll
+      for (int qq = 0; qq < 4; qq++) {
+        bf16x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if constexpr (DBG & 32) pk[e] = (__bf16)(acc[0][ct][4 * qq + e] + acc[1][ct][4 * qq + e]);
+          else pk[e] = (__bf16)gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
+        }
+        *reinterpret_cast<bf16x4 *>(lds + GOFF + ((32 * ct + j) * GS_ + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // every gated column tile frees 32 accumulator registers: the rest of the h patch, then the first half of the skip rows
+    gate_ct(I0{});
+    load_pre(hrs, I2{});
+    __builtin_amdgcn_sched_barrier(0);
+    gate_ct(I1{});
+    load_pre(hrs, I3{});
+    __builtin_amdgcn_sched_barrier(0);
+    gate_ct(I2{});
+    load_pre1(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    gate_ct(I3{});
+    load_pre1(I1{});
+    fetch_bias(I0{});
+    load_a4(p1, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+
+    // ================================================ GEMM2 =========================================================
+    // two passes of 32 rows x 128 columns: pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip (WaveNet.py:93-97,:133)
+    auto gemm2_loop = [&](f32x16(&ac)[4], int pass) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 v = bias[q];
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+          ac[ct][4 * q + 0] = v.x;
+          ac[ct][4 * q + 1] = v.y;
+          ac[ct][4 * q + 2] = v.z;
+          ac[ct][4 * q + 3] = v.w;
+        }
+      }
+      auto mma4b = [&](const bf16x8(&a)[4], const unsigned char *xb) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          bf16x8 bv[4];
+#pragma unroll
+          for (int ct = 0; ct < 4; ct++) bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (GS_ * 2) + s * 32);
+#pragma unroll
+          for (int ct = 0; ct < 4; ct++) {
+            if constexpr (DBG & 64) asm volatile("" ::"v"(a[s]), "v"(bv[ct]));
+            else ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv[ct], ac[ct], 0, 0, 0);
+          }
+        }
+      };
+#pragma unroll 1
+      for (int ks = 0; ks < NKS; ks += 8) {
+        mma4b(p0, gb + ks * 32);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a4(p0, pass * NKS + ks + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        mma4b(p1, gb + (ks + 4) * 32);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a4(p1, pass * NKS + ks + 12);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // epilogue of a pass: MFMA layout (4 rows x 1 column per lane) -> wave-private LDS patch -> 1 row x 4 columns per lane,
+    // so the stores (like the operand loads) are 16 B per lane
+    auto epilogue = [&](const f32x16(&ac)[4], const float(&add)[4][16], const __amdgpu_buffer_rsrc_t &dst, float scale,
+                        auto first_tag) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) {
+        if constexpr (decltype(first_tag)::value) {             // pass 0: the h-patch registers of tiles 0, 1 are free again
+          if (ct == 2) load_pre1(I2{});
+          if (ct == 3) load_pre1(I3{});
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) patch[rowoff(r, hh) * PS_ + j] = ac[ct][r];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const float4 v = *reinterpret_cast<const float4 *>(patch + ((lane >> 3) + 8 * p) * PS_ + 4 * (lane & 7));
+          f32x4 o;
+          o[0] = (add[ct][4 * p + 0] + v.x) * scale;
+          o[1] = (add[ct][4 * p + 1] + v.y) * scale;
+          o[2] = (add[ct][4 * p + 2] + v.z) * scale;
+          o[3] = (add[ct][4 * p + 3] + v.w) * scale;
+          // row step in the VGPR offset, soffset = 0: a >8-byte buffer store with an SGPR soffset reads its data late and
+          // the compiler does not guard the next write of those VGPRs (observed in round 1: torn lanes)
+          if constexpr (DBG & 256) asm volatile("" ::"v"(o));
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst, evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0);
+        }
+      }
+    };
+
+    {
+      f32x16 ac[4];
+      gemm2_loop(ac, 0);
+      fetch_bias(I1{});                                          // ahead of this pass's stores
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue(ac, pre, ors, RS, std::true_type{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- next tile: parameters, and its first X chunk requested BEFORE the last stores of this tile
+    int b_nxt = b_cur, t0_nxt = t0_cur;
+    if (ntile < t_end) tile_bt(ntile, b_nxt, t0_nxt);
+    {
+      f32x16 ac[4];
+      gemm2_loop(ac, 1);
+      __syncthreads();                                           // every wave is done reading the g image / X buffers
+      if (ntile < t_end) {
+        hrs = clip_rsrc(hin, b_nxt);
+        x_geom(t0_nxt, xvoff, xtok);
+        issue_x(hrs, xvoff, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue(ac, pre1, srs, 1.0f, std::false_type{});
+    }
+    b_cur = b_nxt;
+    t0_cur = t0_nxt;
+  }
+}
+
+#ifdef AP_TOOLS
+extern int g_dbg_bf16;
+#endif
+
+// -> 0 launched, 1 shape not served by this kernel (caller falls back to the per-tile kernel)
+int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
+                          int B, int L, hipStream_t st) {
+  const int C = ctx->C, S = ctx->S;
+  const int d = 1 << (layer % ctx->cfg.dilation_cycle);
+  if (C != 256 || S != 256 || (L % 4) != 0 || L < 4 || (d % 4) != 0) return 1;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+      n = 256;
+    n_cu = n;
+  }
+  const int ntiles = (L + PT_ - 1) / PT_;
+  const int nblk = B * ntiles;
+  int grid = nblk < n_cu ? nblk : n_cu;
+  if (grid >= 8) grid &= ~7;
+  // one descriptor per parameter slab, the per-layer tensors addressed by byte offsets inside it
+  const size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
+  const char *wlo = (const char *)ctx->w1p_bf < (const char *)ctx->w2p_bf ? (const char *)ctx->w1p_bf : (const char *)ctx->w2p_bf;
+  const unsigned w1_off = (unsigned)((const char *)ctx->w1p_bf - wlo + layer * n1 * 2);
+  const unsigned w2_off = (unsigned)((const char *)ctx->w2p_bf - wlo + layer * n2 * 2);
+  const unsigned wbytes = (unsigned)((size_t)ctx->NL * (n1 + n2) * 2);
+  const float *blo = ctx->b1 < ctx->b2 ? ctx->b1 : ctx->b2;
+  const float *bhi = ctx->b1 < ctx->b2 ? ctx->b2 : ctx->b1;
+  const unsigned b1_off = (unsigned)((ctx->b1 - blo + (size_t)layer * 2 * C) * 4);
+  const unsigned b2_off = (unsigned)((ctx->b2 - blo + (size_t)layer * (C + S)) * 4);
+  const unsigned bbytes = (unsigned)((bhi - blo + (size_t)ctx->NL * 2 * C) * 4);
+#define AP_P_LAUNCH(D)                                                                                                        \
+  resblock_bf16p_kernel<D><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, \
+                                                           b2_off, L, d, accumulate, ntiles, nblk)
+#ifdef AP_TOOLS
+  switch (g_dbg_bf16 & 0xfff) {
+    case 0: AP_P_LAUNCH(0); break;
+    case 1: AP_P_LAUNCH(1); break;
+    case 2: AP_P_LAUNCH(2); break;
+    case 3: AP_P_LAUNCH(3); break;
+    case 4: AP_P_LAUNCH(4); break;
+    case 7: AP_P_LAUNCH(7); break;
+    case 8: AP_P_LAUNCH(8); break;
+    case 23: AP_P_LAUNCH(23); break;
+    case 31: AP_P_LAUNCH(31); break;
+    case 31 + 128: AP_P_LAUNCH(31 + 128); break;
+    case 31 + 256: AP_P_LAUNCH(31 + 256); break;
+    case 31 + 384: AP_P_LAUNCH(31 + 384); break;
+    case 128: AP_P_LAUNCH(128); break;
+    case 256: AP_P_LAUNCH(256); break;
+    case 384: AP_P_LAUNCH(384); break;
+    case 384 + 1: AP_P_LAUNCH(384 + 1); break;
+    case 384 + 2: AP_P_LAUNCH(384 + 2); break;
+    case 384 + 3: AP_P_LAUNCH(384 + 3); break;
+    case 384 + 8: AP_P_LAUNCH(384 + 8); break;
+    case 384 + 19: AP_P_LAUNCH(384 + 19); break;
+    case 384 + 23: AP_P_LAUNCH(384 + 23); break;
+
+    case 384 + 31 + 64: AP_P_LAUNCH(384 + 31 + 64); break;
+    case 384 + 31 + 96: AP_P_LAUNCH(384 + 31 + 96); break;
+    case 512: AP_P_LAUNCH(512); break;
+    case 512 + 384: AP_P_LAUNCH(512 + 384); break;
+    case 1024: AP_P_LAUNCH(1024); break;
+    case 2048: AP_P_LAUNCH(2048); break;
+    case 1024 + 384: AP_P_LAUNCH(1024 + 384); break;
+    default: set_error("no such DBG instantiation"); return -22;
+  }
+#else
+  AP_P_LAUNCH(0);
+#endif
+#undef AP_P_LAUNCH
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace ap
