@@ -56,6 +56,10 @@ using I3 = std::integral_constant<int, 3>;
 
 }  // namespace
 
+#ifdef AP_TOOLS
+__device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [workgroup][wave][64] s_memtime stamps of one tile
+#endif
+
 // DBG (tools builds only; outputs wrong by construction): 1 no weight loads in GEMM1's loop, 2 no X loads, 4 no pack,
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
 // 256 no stores, 512 no L2 prefetch.
@@ -220,8 +224,23 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   issue_x(hrs, xvoff, 0);
   __syncthreads();                                               // part_t visible
 
+  int tile_iter = 0;
+  auto mark = [&](int i) {
+#ifdef AP_TOOLS
+    if constexpr (DBG & 2048) {
+      if (tile_iter == 6) {                                      // the 7th tile of every workgroup: steady state
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        if (lane == 0) g_ptrace[((size_t)blockIdx.x * NW + wave) * 64 + i] = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
+  };
 #pragma unroll 1
-  for (int tile = t_first; tile < t_end; tile += t_step) {
+  for (int tile = t_first; tile < t_end; tile += t_step, tile_iter++) {
+    mark(0);
     const unsigned keep = xtok ? 0xffffffffu : 0u;
     const int t0 = t0_cur;
     const int ntile = tile + t_step;
@@ -250,7 +269,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll
       for (int rt = 0; rt < 2; rt++) a0[s][rt] = ld_w1(s * 2 + rt);
     pack_all(lds, keep, 0);                                      // chunk 0 was requested during the previous tile
+    issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's light half
+    mark(1);
     __syncthreads();
+    mark(2);
 
     auto mf = [&](const bf16x8 &a, const bf16x8 &bq, int rt, int ct) {
       if constexpr (DBG & 8) {
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll
           for (int rt = 0; rt < 2; rt++) nxt[s][rt] = ld_w1(nfrag + s * 2 + rt);
       }
-      if (with_x) issue_x(hrs, xvoff, xch);
+      (void)xch; (void)with_x;
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         bf16x8 bv[4];
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll
       for (int i = 0; i < 24; i++) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         if ((i & 7) >= 3 && (i & 7) <= 6 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -343,6 +365,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           mf(use[s][1], bv[ct], 1, ct);
           if (s < 2) rdb(bv[ct], xb, ct, s + 1);
           if constexpr (!LAST) {
+            // the staging registers are free again: request the chunk after next right away (its pack is one chunk away)
+            if (s == 2 && ct == 0 && pch + 1 < NCH) issue_x(hrs, xvoff, pch + 1);
+          }
+          if constexpr (!LAST) {
             if (s == 0 && ct < 2 && !(DBG & 1)) nxt[2][ct] = ld_w1(nfrag + 4 + ct);
             if (s == 1 && ct == 0) pack_piece(pdst, keep, I0{}, I1{});
             if (s == 1 && ct == 1) pack_piece(pdst, keep, I1{}, I1{});
@@ -358,13 +384,18 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     for (int ch = 0; ch < NCH - 1; ch++) {
       const unsigned char *xb = lds + (ch & 1) * XBYTES + rdoff;
       half_heavy(a0, xb, a1, ch * 12 + 6, ch + 1, true);
+      mark(3 + ch * 3);
       half_light(a1, xb + 3 * 32, a0, (ch + 1) * 12, lds + ((ch + 1) & 1) * XBYTES, ch + 1, std::false_type{});
+      mark(4 + ch * 3);
       if constexpr (!(DBG & 512)) __syncthreads();              // DBG 512 (timing only): no per-chunk barrier
+      mark(5 + ch * 3);
     }
     {
       const unsigned char *xb = lds + ((NCH - 1) & 1) * XBYTES + rdoff;
       half_heavy(a0, xb, a1, (NCH - 1) * 12 + 6, 0, false);
+      mark(24);
       half_light(a1, xb + 3 * 32, a0, 0, nullptr, 0, std::true_type{});
+      mark(25);
     }
 
     // ================================================ gate ==========================================================
@@ -441,7 +472,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     fetch_bias(I0{});
     load_a4(p1, 4);
     __builtin_amdgcn_sched_barrier(0);
+    mark(26);
     __syncthreads();
+    mark(27);
 
     // ================================================ GEMM2 =========================================================
     // two passes of 32 rows x 128 columns: pass 0 = res_conv rows -> h', pass 1 = skip_conv rows -> skip (WaveNet.py:93-97,:133)
@@ -457,27 +490,29 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           ac[ct][4 * q + 3] = v.w;
         }
       }
-      auto mma4b = [&](const bf16x8(&a)[4], const unsigned char *xb) {
+      // B fragments (g image) are read one k-step ahead into the other of two register sets: the LDS latency of a k-step's
+      // four reads hides behind the previous k-step's four MFMAs (read just before use it was exposed 32 times per tile)
+      bf16x8 ba[4], bb[4];
+      auto rdg = [&](bf16x8(&bq)[4], int ks) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-          bf16x8 bv[4];
-#pragma unroll
-          for (int ct = 0; ct < 4; ct++) bv[ct] = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (GS_ * 2) + s * 32);
-#pragma unroll
-          for (int ct = 0; ct < 4; ct++) {
-            if constexpr (DBG & 64) asm volatile("" ::"v"(a[s]), "v"(bv[ct]));
-            else ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bv[ct], ac[ct], 0, 0, 0);
-          }
-        }
+        for (int ct = 0; ct < 4; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(gb + (32 * ct) * (GS_ * 2) + (ks & (NKS - 1)) * 32);
       };
+      auto step = [&](const bf16x8 &a, const bf16x8(&use)[4], bf16x8(&nxt)[4], int ks) {
+        rdg(nxt, ks + 1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ct++) {
+          if constexpr (DBG & 64) asm volatile("" ::"v"(a), "v"(use[ct]));
+          else ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, use[ct], ac[ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      rdg(ba, 0);
 #pragma unroll 1
       for (int ks = 0; ks < NKS; ks += 8) {
-        mma4b(p0, gb + ks * 32);
-        __builtin_amdgcn_sched_barrier(0);
+        step(p0[0], ba, bb, ks + 0); step(p0[1], bb, ba, ks + 1); step(p0[2], ba, bb, ks + 2); step(p0[3], bb, ba, ks + 3);
         load_a4(p0, pass * NKS + ks + 8);
         __builtin_amdgcn_sched_barrier(0);
-        mma4b(p1, gb + (ks + 4) * 32);
-        __builtin_amdgcn_sched_barrier(0);
+        step(p1[0], ba, bb, ks + 4); step(p1[1], bb, ba, ks + 5); step(p1[2], ba, bb, ks + 6); step(p1[3], bb, ba, ks + 7);
         load_a4(p1, pass * NKS + ks + 12);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -513,9 +548,11 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     {
       f32x16 ac[4];
       gemm2_loop(ac, 0);
+      mark(28);
       fetch_bias(I1{});                                          // ahead of this pass's stores
       __builtin_amdgcn_sched_barrier(0);
       epilogue(ac, pre, ors, RS, std::true_type{});
+      mark(29);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -525,7 +562,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     {
       f32x16 ac[4];
       gemm2_loop(ac, 1);
+      mark(30);
       __syncthreads();                                           // every wave is done reading the g image / X buffers
+      mark(31);
       if (ntile < t_end) {
         hrs = clip_rsrc(hin, b_nxt);
         x_geom(t0_nxt, xvoff, xtok);
@@ -533,6 +572,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);
       epilogue(ac, pre1, srs, 1.0f, std::false_type{});
+      mark(32);
     }
     b_cur = b_nxt;
     t0_cur = t0_nxt;
@@ -541,6 +581,12 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 
 #ifdef AP_TOOLS
 extern int g_dbg_bf16;
+}  // namespace ap
+extern "C" int ap_debug_ptrace(void *buf) {                       // device buffer of grid x 8 x 64 u64 (tools/trace_resblock_bf16p.py)
+  unsigned long long *p = (unsigned long long *)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ap::g_ptrace), &p, sizeof(p));
+}
+namespace ap {
 #endif
 
 // -> 0 launched, 1 shape not served by this kernel (caller falls back to the per-tile kernel)
@@ -604,6 +650,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     case 512 + 384: AP_P_LAUNCH(512 + 384); break;
     case 1024: AP_P_LAUNCH(1024); break;
     case 2048: AP_P_LAUNCH(2048); break;
+    case 2048 + 384: AP_P_LAUNCH(2048 + 384); break;
     case 1024 + 384: AP_P_LAUNCH(1024 + 384); break;
     default: set_error("no such DBG instantiation"); return -22;
   }
