@@ -657,11 +657,14 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
     set_error("AP_PREC_BF16 is built for res_channels = 256 only (got %d)", C);
     return -22;
   }
+  // dispatch: the persistent kernel (ap_resblock_bf16p.hip) where it serves the shape, else this file's per-tile kernel
+  // (any d, any L).  Tools builds can force the per-tile kernel for A/B timing (ap_debug_bf16_dbg bit 0x1000).
 #ifdef AP_TOOLS
-  if (!(g_dbg_bf16 & 0x1000) && !g_trace_bf16)                  // 0x1000: force the per-tile kernel below (A/B timing)
+  const bool force_tile = (g_dbg_bf16 & 0x1000) != 0;
+  if (!force_tile && !g_trace_bf16)
 #endif
   {
-    const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);   // persistent form
+    const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
     if (rc != 1) return rc;                                      // 1: shape not served there (d % 4, L % 4) -> per-tile kernel
   }
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);

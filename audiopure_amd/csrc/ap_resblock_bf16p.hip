@@ -233,6 +233,11 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         unsigned long long t;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
         if (lane == 0) g_ptrace[((size_t)blockIdx.x * NW + wave) * 64 + i] = t;
+        if (i == 0 || i == 32) {                                 // wall clock (100 MHz) beside the shader clock: their ratio is the
+          unsigned long long rt;                                 // clock the chip holds under this kernel
+          asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+          if (lane == 0) g_ptrace[((size_t)blockIdx.x * NW + wave) * 64 + 40 + (i == 32)] = rt;
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }

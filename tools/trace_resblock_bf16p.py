@@ -29,7 +29,8 @@ for ch in range(7):
     names[3 + ch * 3] = f"chunk {ch} heavy half"; names[4 + ch * 3] = f"chunk {ch} light half (+pack)"; names[5 + ch * 3] = f"chunk {ch} barrier"
 names[24] = "chunk 7 heavy half"; names[25] = "chunk 7 light half"
 tot = np.median(t[:, :, 32] - t[:, :, 0])
-print(f"layer {layer} B={B} dbg {2048 + extra}: median tile = {tot:.0f} cycles")
+rt = np.median(t[:, :, 41] - t[:, :, 40])
+print(f"layer {layer} B={B} dbg {2048 + extra}: median tile = {tot:.0f} shader cycles = {rt:.0f} ticks of 100 MHz -> {tot / rt * 0.1:.3f} GHz")
 acc = {}
 for i in range(1, 33):
     dseg = t[:, :, i] - t[:, :, i - 1]
