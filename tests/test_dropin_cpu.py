@@ -68,6 +68,13 @@ def test_script_imports_resolve_to_the_native_path_from_inside_the_reference_che
     out = _run(SCRIPT_IMPORTS + """
     import robustness_eval.black_box_attack as bb          # the reference's own module, found through extend_path
     assert bb.NES.__module__ == "audiopure_amd.robustness_eval._NES", bb.NES.__module__
+    from diffusion_models.diffwave_ddpm import DiffWave    # transfer_attack_eval.py:9
+    assert DiffWave.__module__ == "audiopure_amd.diffusion_models.diffwave_ddpm"
+    from audio_models.RCNN_KWS import *                    # kws_adaptive_attack_eval.py:71
+    assert KWSModel.__module__ == "audiopure_amd.audio_models.RCNN_KWS.model", KWSModel.__module__
+    Classifier = KWSModel(in_size=40)                      # :74
+    from diffusion_models.improved_diffusion_sde import *  # adaptive_attack_eval.py:103
+    assert RevImprovedDiffusion.__module__ == "audiopure_amd.diffusion_models.improved_diffusion_sde"
     """, with_reference=True)
     assert "OK" in out
 
