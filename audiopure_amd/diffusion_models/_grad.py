@@ -7,8 +7,9 @@ Every sampler here is a chain of links ``x <- ca x + cb eps(x, t) + cs z`` (``ap
 
     dL/dx_t = ca dL/dx_{t-1} + cb J_eps(x_t, t)^T dL/dx_{t-1}
 
-with the states x_t check-pointed in the forward pass and one eps-evaluation recomputed per link in the backward
-pass (the adjoint's memory/compute trade: only the 37 layer inputs of ONE evaluation are ever live).
+with the states x_t check-pointed in the forward pass.  A link's 37 layer inputs are kept for the backward pass while the
+chain fits a memory budget (``SAVE_BUDGET_BYTES``; 288 GB of HBM hold a PGD batch comfortably) and recomputed otherwise
+(the adjoint's memory/compute trade).
 
 ``J_eps^T v`` runs on the HIP library: the residual blocks' forward is the fused kernel (``ap_resblock_fwd``), the
 three GEMM-shaped backward terms of a block -- the recomputed dilated conv, ``W2^T [dh'; dskip]`` and the transposed
@@ -171,17 +172,35 @@ def _axpby(x, y, a, b):
     return out
 
 
+SAVE_BUDGET_BYTES = 48 << 30      # per chain: keep the links' layer inputs when they fit (288 GB of HBM), else recompute
+
+
+def _saved_bytes(saved) -> int:
+    n = 0
+    stack = [saved]
+    while stack:
+        o = stack.pop()
+        if isinstance(o, torch.Tensor):
+            n += o.numel() * o.element_size()
+        elif isinstance(o, (tuple, list)):
+            stack.extend(o)
+        elif isinstance(o, dict):
+            stack.extend(o.values())
+    return n
+
+
 class _ChainFn(torch.autograd.Function):
     """x_out = chain(x_in): q-sample then the links (step, ca, cb, cs); noise tensors given explicitly.
 
-    The forward pass keeps only the state entering each link: its eps-evaluations run without per-layer saves
-    (``grad.eps_only`` = the plain fused forward) and every elementwise update is an ``ap_axpbyc`` call.  The backward
-    pass recomputes one evaluation per link with saves (``grad.forward_save``) and applies its J^T."""
+    Every elementwise update is an ``ap_axpbyc`` call.  A link's eps-evaluation keeps its per-layer inputs for the backward
+    pass while the chain's total stays under ``SAVE_BUDGET_BYTES`` (one evaluation of the shipped net is 0.6 GB per clip:
+    a PGD batch of 8 clips x 5 links is 24 GB of the 288); beyond the budget only the state entering the link is kept and
+    the evaluation is recomputed in the backward pass (the adjoint's trade: compute for memory)."""
 
     @staticmethod
     def forward(ctx, x, grad, steps, qa, qs, zs):
         """zs[k] = draw k of the chain ([B,1,L] or [B,L]); draw 0 is the q-sample's (the numbering of ap_purify_chain)."""
-        xs = []
+        xs, saves, held = [], [], 0
         cur = x.detach().float().contiguous()
         eps_only = getattr(grad, "eps_only", None)
         with torch.no_grad():
@@ -189,22 +208,39 @@ class _ChainFn(torch.autograd.Function):
                 cur = _axpby(cur, zs[0], qa, qs)
             elif qa != 1.0:
                 cur = _axpby(cur, None, qa, 0.0)
+            per_link = None
             for (t, ca, cb, cs, draw) in steps:
                 xs.append(cur)
-                eps = eps_only(cur, t) if eps_only is not None else grad.forward_save(cur, t)[0]
+                keep = per_link is None or held + per_link <= SAVE_BUDGET_BYTES
+                if keep:
+                    eps, saved = grad.forward_save(cur, t)
+                    if per_link is None:
+                        per_link = _saved_bytes(saved)
+                        if per_link > SAVE_BUDGET_BYTES:
+                            saved = None
+                    if saved is not None:
+                        held += per_link
+                    saves.append(saved)
+                else:
+                    eps = eps_only(cur, t) if eps_only is not None else grad.forward_save(cur, t)[0]
+                    saves.append(None)
                 nxt = _axpby(cur, eps, ca, cb)
                 if cs != 0.0 and draw:
                     nxt = _axpby(nxt, zs[draw], 1.0, cs)
                 cur = nxt
-        ctx.grad, ctx.steps, ctx.qa, ctx.xs = grad, steps, qa, xs
+        ctx.grad, ctx.steps, ctx.qa, ctx.xs, ctx.saves = grad, steps, qa, xs, saves
         return cur
 
     @staticmethod
     def backward(ctx, g):
         g = g.detach().float().contiguous()
         with torch.no_grad():
-            for (t, ca, cb, cs, draw), xt in zip(reversed(ctx.steps), reversed(ctx.xs)):
-                _, saved = ctx.grad.forward_save(xt, t)          # recompute this link's evaluation (adjoint-style)
+            for k in range(len(ctx.steps) - 1, -1, -1):
+                (t, ca, cb, cs, draw), xt = ctx.steps[k], ctx.xs[k]
+                saved = ctx.saves[k]
+                ctx.saves[k] = None
+                if saved is None:
+                    _, saved = ctx.grad.forward_save(xt, t)      # over budget in the forward pass: recompute this link
                 g = _axpby(g, ctx.grad.backward(saved, g), ca, cb)
                 del saved
             if ctx.qa != 1.0:
