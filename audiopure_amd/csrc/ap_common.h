@@ -76,6 +76,7 @@ struct ap_ctx {
   float *bf1, *wf2, *bf2; // [S], [S], [1]
   float *w1p, *w2p, *wf1p;  // packed fp32 MFMA A-operand images
   void *w1p_bf, *w2p_bf;    // packed bf16 images (AP_PREC_BF16), own allocation
+  void *wf1p_bf;            // final conv's first 1x1 as a bf16 image (same allocation)
   void *slab_bf;
   void *w1p_s, *w2p_s;      // 3-way bf16-split images (AP_PREC_F32_SPLIT), own allocation
   void *slab_s;
@@ -108,6 +109,9 @@ int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *e
 int launch_affine_noise(const float *x, float *out, float ca, float cs, const float *z, uint64_t seed,
                         uint32_t draw, uint64_t utt_offset, int B, int L, hipStream_t st);
 int launch_pack_bf16(ap_ctx *ctx, hipStream_t st);
+int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca, float cb,
+                             float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
+                             hipStream_t st);                    // returns 1 if the shape is not served (caller: fp32 kernel)
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,

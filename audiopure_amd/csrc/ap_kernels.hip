@@ -754,9 +754,149 @@ __global__ __launch_bounds__(S / 64 * 64, FT == 64 ? 2 : 1) void final_f32_kerne
   }
 }
 
+// The same final_conv + update with bf16 MFMA operands (AP_PREC_BF16; fp32 accumulate, fp32 skip in HBM): at S = 256 the
+// fp32 kernel above is MFMA-bound (1.07 TFLOP per 512-clip launch on the fp32 pipe = 13.8 ms, 3.7 % of a bf16 step); on the
+// bf16 pipe the launch is bound by reading skip once.  4 waves x 64 rows, 64-column tiles, two workgroups per CU; skip is
+// staged as a bf16 [column][channel] image (528-B rows: conflict-free ds_read_b128 B fragments).
+typedef __bf16 fb16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256, 2) void final_bf16_kernel(
+    const float *__restrict__ skip, const float *__restrict__ x, float *__restrict__ eps_out, float *__restrict__ out,
+    const fb16x8 *__restrict__ wfp, const float *__restrict__ bf1, const float *__restrict__ wf2,
+    const float *__restrict__ bf2, float scale, float ca, float cb, float cs, const float *__restrict__ z, uint64_t seed,
+    uint32_t draw, uint64_t utt_offset, int L, int ntiles) {
+  constexpr int S = 256, FT = 64, NW = 4, RB = S * 2 + 16, NKS = S / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char img[FT * RB];
+  __shared__ float red[NW * FT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.x / ntiles;
+  const int t0 = (blockIdx.x % ntiles) * FT;
+  const float *sk = skip + (size_t)b * S * L;
+  // stage skip * sqrt(1/N) -> bf16 image; item = (column quad cq of 16, channel octet oct of 32): 4 samples x 8 channels
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int item = tid + 256 * r, cq = item & 15, oct = item >> 4;
+    const int t = t0 + 4 * cq;
+    float v[8][4];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const float *row = sk + (size_t)(oct * 8 + e) * L;
+      if ((L & 3) == 0) {
+        const float4 q = t < L ? *reinterpret_cast<const float4 *>(row + t) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[e][0] = q.x; v[e][1] = q.y; v[e][2] = q.z; v[e][3] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[e][i] = t + i < L ? row[t + i] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      fb16x8 pk;
+#pragma unroll
+      for (int e = 0; e < 8; e++) pk[e] = (__bf16)(v[e][i] * scale);
+      *reinterpret_cast<fb16x8 *>(img + (4 * cq + i) * RB + oct * 16) = pk;
+    }
+  }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float bv = bf1[64 * wave + 32 * rt + rowoff(r, hh)];
+      acc[rt][0][r] = bv;
+      acc[rt][1][r] = bv;
+    }
+  __syncthreads();
+  // image [wave][rowtile 2][kstep 16][lane][8 bf16]; fragments two k-steps ahead
+  const fb16x8 *ap = wfp + (size_t)(wave * 2) * NKS * 64 + lane;
+  fb16x8 a0[2], a1[2], a2[2];
+  a0[0] = ap[0]; a0[1] = ap[NKS * 64];
+  a1[0] = ap[64]; a1[1] = ap[NKS * 64 + 64];
+  const unsigned char *bp = img + j * RB + 16 * hh;
+  auto kstep = [&](const fb16x8(&a)[2], int ks) {
+    fb16x8 bv[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) bv[ct] = *reinterpret_cast<const fb16x8 *>(bp + (32 * ct) * RB + ks * 32);
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+  };
+  auto fetch = [&](fb16x8(&a)[2], int ks) {
+    const int k2 = ks < NKS ? ks : NKS - 1;
+    a[0] = ap[k2 * 64];
+    a[1] = ap[NKS * 64 + k2 * 64];
+  };
+#pragma unroll 1
+  for (int ks = 0; ks < NKS; ks += 3) {                         // 16 k-steps: 5 rounds of 3 + 1
+    fetch(a2, ks + 2);
+    kstep(a0, ks);
+    if (ks + 1 < NKS) {
+      fetch(a0, ks + 3);
+      kstep(a1, ks + 1);
+    }
+    if (ks + 2 < NKS) {
+      fetch(a1, ks + 4);
+      kstep(a2, ks + 2);
+    }
+  }
+  // relu, dot with W_f2 over this wave's 64 rows
+  float part[2] = {0.f, 0.f};
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float w = wf2[64 * wave + 32 * rt + rowoff(r, hh)];
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) part[ct] = __builtin_fmaf(fmaxf(acc[rt][ct][r], 0.f), w, part[ct]);
+    }
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) part[ct] += __shfl_xor(part[ct], 32);
+  if (hh == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) red[wave * FT + 32 * ct + j] = part[ct];
+  }
+  __syncthreads();
+  if (tid < FT) {
+    const int t = t0 + tid;
+    if (t < L) {
+      float e = bf2[0];
+#pragma unroll
+      for (int w = 0; w < NW; w++) e += red[w * FT + tid];
+      const size_t off = (size_t)b * L + t;
+      if (eps_out) eps_out[off] = e;
+      if (out) {
+        float v = ca * x[off] + cb * e;
+        if (cs != 0.f) {
+          const float zv = z ? z[off] : philox_normal1(seed, draw, utt_offset + b, t);
+          v += cs * zv;
+        }
+        out[off] = v;
+      }
+    }
+  }
+}
+
+int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca, float cb,
+                             float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
+                             hipStream_t st) {
+  if (ctx->S != 256 || !ctx->wf1p_bf) return 1;
+  const int ntiles = (L + 63) / 64;
+  const float scale = (float)sqrt(1.0 / (double)ctx->NL);      // math.sqrt(1.0/N) (WaveNet.py:135)
+  final_bf16_kernel<<<(unsigned)B * ntiles, 256, 0, st>>>(skip, x, eps_out, out, (const fb16x8 *)ctx->wf1p_bf, ctx->bf1, ctx->wf2,
+                                                          ctx->bf2, scale, ca, cb, cs, z, seed, draw, utt_offset, L, ntiles);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st) {
+  if (ctx->cfg.precision == AP_PREC_BF16) {                     // bf16 mode: the 1x1 convs of final_conv on the bf16 pipe as well
+    const int rc = launch_final_affine_bf16(ctx, skip, x, eps_out, out, ca, cb, cs, z, seed, draw, utt_offset, B, L, st);
+    if (rc != 1) return rc;
+  }
   const int S = ctx->S;
   const int ft = (S == 256) ? 64 : TT;
   const int ntiles = (L + ft - 1) / ft;

@@ -73,6 +73,22 @@ __global__ void pack_w2_bf16_kernel(const float *__restrict__ w2f, __bf16 *__res
   out[idx] = (__bf16)w2f[(size_t)o * C + k];
 }
 
+// final conv's first 1x1: [wave S/64][rowtile 2][kstep S/16][lane 64][8]; wave w owns output rows [64w, 64w+64)
+__global__ void pack_wf1_bf16_kernel(const float *__restrict__ wf1f, __bf16 *__restrict__ out, int S) {
+  const int NKS = S / 16;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)S * S) return;
+  int jj = idx & 7;
+  int lane = (idx >> 3) & 63;
+  size_t rest = idx >> 9;
+  int ks = rest % NKS; rest /= NKS;
+  int rt = rest & 1;
+  int w = rest >> 1;
+  int k = ks * 16 + 8 * (lane >> 5) + jj;
+  int o = 64 * w + 32 * rt + (lane & 31);
+  out[idx] = (__bf16)wf1f[(size_t)o * S + k];
+}
+
 int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
   const int C = ctx->C, S = ctx->S, NL = ctx->NL;
   for (int n = 0; n < NL; n++) {
@@ -80,6 +96,8 @@ int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
     pack_w1_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1p_bf + n * n1, C);
     pack_w2_bf16_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, (__bf16 *)ctx->w2p_bf + n * n2, C);
   }
+  if (ctx->wf1p_bf && S % 64 == 0)
+    pack_wf1_bf16_kernel<<<(unsigned)(((size_t)S * S + 255) / 256), 256, 0, st>>>(ctx->wf1f, (__bf16 *)ctx->wf1p_bf, S);
   AP_HIP(hipGetLastError());
   return 0;
 }

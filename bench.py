@@ -339,7 +339,7 @@ def main():
                     "executed_f16_TFLOPs": round(3 * achieved, 1)}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "resblock_bf16_kernel<256>", "achieved": round(gbs, 1), "peak": 8000.0,
+            roof = {"bound": "hbm", "kernel": "resblock_bf16p_kernel (persistent; layers with d = 1, 2: resblock_bf16_kernel<256>)", "achieved": round(gbs, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic,
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
         roof.update({"traffic_source": traffic_source, "launches": launches, "avg_launch_ms": round(k_ms, 4),

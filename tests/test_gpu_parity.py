@@ -683,3 +683,26 @@ def test_purify_is_hip_graph_capturable(mini, dh, dev):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(static_out, ref)
+
+
+def test_bf16_final_conv_close_to_the_fp32_one(dev):
+    """AP_PREC_BF16 runs final_conv's 1x1 convs on the bf16 pipe too (fp32 accumulate): eps and the fused update agree with
+    the fp32 kernel to bf16 operand rounding, ragged last tile and L % 4 != 0 included."""
+    from audiopure_amd import _native as N
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    nf, _ = _net(cfg, dev)
+    nb, _ = _net(cfg, dev)
+    nb.set_precision("bf16")
+    ef, eb = nf.engine(), nb.engine()
+    for B, L in ((2, 16000), (3, 1500), (2, 130), (1, 1001)):
+        skip = torch.from_numpy(synth.uniform(f"fsk/{L}", (B, 256, L), 2, -6.0, 6.0)).to(dev)
+        x = torch.from_numpy(synth.uniform(f"fx/{L}", (B, 1, L), 2, -1.0, 1.0)).to(dev)
+        zt = torch.from_numpy(synth.uniform(f"fz/{L}", (B, 1, L), 2, -1.0, 1.0)).to(dev)
+        outs = []
+        for eng in (ef, eb):
+            eps, out = torch.empty_like(x), torch.empty_like(x)
+            N.check(eng.lib.ap_final_affine(eng.ctx, N.ptr(skip), N.ptr(x), N.ptr(eps), N.ptr(out), 1.01, -0.2, 0.05, N.ptr(zt),
+                                            0, 0, 0, B, L, N.stream()))
+            outs.append((eps.cpu().numpy(), out.cpu().numpy()))
+        assert rel_err(outs[1][0], outs[0][0]) < 1e-2, (B, L)
+        assert rel_err(outs[1][1], outs[0][1]) < 1e-2, (B, L)
