@@ -313,3 +313,26 @@ def test_config4_unet_ddpm_n5_resnext_matches_reference_golden_and_scales_to_b25
     big = system(big_img, True)
     assert big.shape == (B, 10) and torch.isfinite(big).all()
     assert rel_err(big[:2].cpu().numpy(), golden2["unetfull/ddpm_n5_logits"]) < 2e-3
+
+
+def test_rev_diffwave_sample_step_two_chains_the_purifier_like_the_reference(mini, dh, dev):
+    """diffwave_sde.py:182-212: with sample_step = 2 the second pass purifies the FIRST pass's output and both are returned,
+    concatenated along the batch axis; each pass consumes its own t + 1 draws."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    from oracle import diffwave_oracle as O
+    dw = DiffWave(model=mini, diffusion_hyperparams=dh, reverse_timestep=3)
+    args = types.SimpleNamespace(t=3, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=2,
+                                 ddpm_path=None, ddpm_config=None)
+    rev = RevDiffWave.from_model(dw, args)
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=7))
+    z = [torch.from_numpy(synth.noise(d, 2, 16000, seed=7)) for d in range(8)]
+    dw.set_noise_source(list(z))
+    got = rev(x0.to(dev))
+    assert got.shape == (4, 1, 16000) and dw._noise == []
+    cfg = synth.mini_wavenet_config(64, 12, 12)
+    w = O.fold_state_dict(synth.wavenet_state_dict(cfg, 0))
+    x1 = O.sde_purify(w, cfg, O.sde_tables(), x0, 3, z[:4])
+    x2 = O.sde_purify(w, cfg, O.sde_tables(), x1, 3, z[4:])
+    assert rel_err(got[:2].cpu().numpy(), x1.numpy()) < TOL_CHAIN
+    assert rel_err(got[2:].cpu().numpy(), x2.numpy()) < 2 * TOL_CHAIN
