@@ -49,6 +49,20 @@ __device__ __forceinline__ float gate_fast(float a, float b) {
   return __builtin_copysignf(g, a);
 }
 
+// the gate on a pair of values: the plain arithmetic as two-wide fp32 vector operations (v_pk_add_f32 / v_pk_mul_f32: one
+// issue slot for two gates; the file is built with -fno-slp-vectorize, so the pairing is written out), the three
+// transcendentals per gate stay scalar.  Same formula as gate_fast.
+__device__ __forceinline__ f32x2 gate_fast2(f32x2 a, f32x2 b) {
+  const f32x2 ea = f32x2{__builtin_fabsf(a[0]), __builtin_fabsf(a[1])} * -2.885390081777926815f;
+  const f32x2 eb = b * -1.442695040888963407f;
+  const f32x2 E = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+  const f32x2 F = {__builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+  const f32x2 den = (E + 1.0f) * (F + 1.0f);
+  const f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 g = (1.0f - E) * r;
+  return f32x2{__builtin_copysignf(g[0], a[0]), __builtin_copysignf(g[1], a[1])};
+}
+
 using I0 = std::integral_constant<int, 0>;
 using I1 = std::integral_constant<int, 1>;
 using I2 = std::integral_constant<int, 2>;
@@ -454,9 +468,12 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       for (int qq = 0; qq < 4; qq++) {
         bf16x4 pk;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-          if constexpr (DBG & 32) pk[e] = (__bf16)(acc[0][ct][4 * qq + e] + acc[1][ct][4 * qq + e]);
-          else pk[e] = (__bf16)gate_fast(acc[0][ct][4 * qq + e], acc[1][ct][4 * qq + e]);
+        for (int e = 0; e < 4; e += 2) {
+          const f32x2 a2 = {acc[0][ct][4 * qq + e], acc[0][ct][4 * qq + e + 1]};
+          const f32x2 b2 = {acc[1][ct][4 * qq + e], acc[1][ct][4 * qq + e + 1]};
+          const f32x2 g2 = (DBG & 32) ? a2 + b2 : gate_fast2(a2, b2);
+          pk[e] = (__bf16)g2[0];
+          pk[e + 1] = (__bf16)g2[1];
         }
         *reinterpret_cast<bf16x4 *>(lds + GOFF + ((32 * ct + j) * GS_ + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
       }
