@@ -76,7 +76,7 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 
 // DBG (tools builds only; outputs wrong by construction): 1 no weight loads in GEMM1's loop, 2 no X loads, 4 no pack,
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
-// 256 no stores, 512 no L2 prefetch.
+// 256 no stores, 512 no per-chunk barrier, 1024 every tile stages clip 0, 2048 phase stamps, 0x2000 no priority swap.
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   constexpr int GOFF = 2 * XBYTES;
   constexpr int POFF = GOFF + PT_ * GS_ * 2;                   // output patches: 8 waves x 32 x 32 fp32
   constexpr int PTOFF = POFF + NW * 32 * PS_ * 4;              // part_t (C floats)
-  constexpr int LDS_BYTES = PTOFF + C * 4;
+  constexpr int BOFF = PTOFF + C * 4;                          // b1 (2C floats: filter | gate rows), b2 (2C: res | skip rows)
+  constexpr int LDS_BYTES = BOFF + 4 * C * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -133,6 +134,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   const float *ptx = reinterpret_cast<const float *>(lds + PTOFF) + oct * 8;
 
   if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
+  // the bias vectors live in LDS for the whole kernel: fetched per tile from memory they sat behind the previous tile's
+  // stores in the in-order vmcnt queue, kept in registers they spilled
+  {
+    const unsigned char *bb = static_cast<const unsigned char *>(bbase);
+    reinterpret_cast<float *>(lds + BOFF)[tid] = reinterpret_cast<const float *>(bb + b1_off)[tid];
+    reinterpret_cast<float *>(lds + BOFF)[2 * C + tid] = reinterpret_cast<const float *>(bb + b2_off)[tid];
+  }
 
   float xr[32];
   auto tile_bt = [&](int tile, int &b, int &t0) {
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t wrs = uni_rsrc(wbase, wbytes);
-  const __amdgpu_buffer_rsrc_t brs = uni_rsrc(bbase, bbytes);
+  (void)bbytes;
   const unsigned lane16 = (unsigned)lane * 16u;
   // GEMM1 image [wave][chunk][kstep 6][rowtile 2][lane][8 bf16]: fragment f of this wave = f KB from the wave's base
   auto ld_w1 = [&](int frag) {
@@ -235,8 +243,20 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   unsigned xvoff;
   bool xtok;
   x_geom(t0_cur, xvoff, xtok);
-  issue_x(hrs, xvoff, 0);
-  __syncthreads();                                               // part_t visible
+  // a tile's first X chunk and first weight fragments are requested at the END of the previous tile, ahead of that tile's
+  // last stores (here for the first tile): a request issued after a store cannot be waited for without waiting for the
+  // store (vmcnt retires in order)
+  unsigned keep = xtok ? 0xffffffffu : 0u;
+  bf16x8 a0[3][2];
+  auto tile_head = [&]() {
+    issue_x(hrs, xvoff, 0);
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++) a0[s][rt] = ld_w1(s * 2 + rt);
+  };
+  tile_head();
+  __syncthreads();                                               // part_t, biases visible
 
   int tile_iter = 0;
   auto mark = [&](int i) {
@@ -260,20 +280,15 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll 1
   for (int tile = t_first; tile < t_end; tile += t_step, tile_iter++) {
     mark(0);
-    const unsigned keep = xtok ? 0xffffffffu : 0u;
     const int t0 = t0_cur;
     const int ntile = tile + t_step;
-    // the bias vectors are re-fetched per tile (L2 / scalar-cache hits): hoisted out of the tile loop they would occupy 64
-    // registers for the whole kernel and spill -- the empty asm makes the pointers opaque per iteration
-    unsigned bias_tok = 0;
-    asm volatile("" : "+s"(bias_tok));
     // ================================================ GEMM1 =========================================================
     f32x16 acc[2][4];
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const f32x4 bv4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)hh * 16u, b1_off + (rt * C + 32 * wave + 8 * q) * 4 + bias_tok, 0));
+        const f32x4 bv4 = *reinterpret_cast<const f32x4 *>(lds + BOFF + (rt * C + 32 * wave + 8 * q + 4 * hh) * 4);
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) {
           acc[rt][ct][4 * q + 0] = bv4[0];
@@ -282,12 +297,8 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           acc[rt][ct][4 * q + 3] = bv4[3];
         }
       }
-    bf16x8 a0[3][2], a1[3][2];
-#pragma unroll
-    for (int s = 0; s < 3; s++)
-#pragma unroll
-      for (int rt = 0; rt < 2; rt++) a0[s][rt] = ld_w1(s * 2 + rt);
-    pack_all(lds, keep, 0);                                      // chunk 0 was requested during the previous tile
+    bf16x8 a1[3][2];
+    pack_all(lds, keep, 0);
     issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's light half
     mark(1);
     __syncthreads();
@@ -308,6 +319,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     // (8 loads), one between each of the first MFMAs (the CU's memory pipe takes a wave-wide load every ~16 cycles)
     auto half_heavy = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], int nfrag, int xch,
                           bool with_x) {
+      // the two waves of a SIMD: the older one (waves 0-3) wins every issue conflict and reached the chunk barrier ~1.2 k
+      // cycles ahead of the younger one, which then finished alone with its stalls exposed (tools/trace_resblock_bf16p.py).
+      // The younger wave gets the priority in this half, the older one (by age) in the other half: -1.3 % block time.
+      if constexpr (!(DBG & 0x2000)) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
       if constexpr (!(DBG & 1)) {
 #pragma unroll
         for (int s = 0; s < 3; s++)
@@ -363,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     auto half_light = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], int nfrag,
                           unsigned char *pdst, int pch, auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
+      if constexpr (!(DBG & 0x2000)) __builtin_amdgcn_s_setprio(0);
       bf16x8 bv[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xb, ct, 0);
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = 32 * wave + 8 * q + 4 * hh;
-        const f32x4 v4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)hh * 16u, b2_off + (pass * C + 32 * wave + 8 * q) * 4 + bias_tok, 0));
+        const f32x4 v4 = *reinterpret_cast<const f32x4 *>(lds + BOFF + (2 * C + pass * C + 32 * wave + 8 * q + 4 * hh) * 4);
         float4 v = make_float4(v4[0], v4[1], v4[2], v4[3]);
         if (pass == 0) {                                         // u = h + part_t re-enters the residual (alias semantics)
           const float4 pv = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lds + PTOFF) + c);
@@ -581,17 +597,19 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     // ---- next tile: parameters, and its first X chunk requested BEFORE the last stores of this tile
     int b_nxt = b_cur, t0_nxt = t0_cur;
     if (ntile < t_end) tile_bt(ntile, b_nxt, t0_nxt);
+    // (unconditional from here: after its last tile a workgroup re-requests that tile's first chunk and drops it -- a
+    // conditional request would keep the staging and fragment registers live across the whole tile)
+    hrs = clip_rsrc(hin, b_nxt);
+    x_geom(t0_nxt, xvoff, xtok);
+    keep = xtok ? 0xffffffffu : 0u;
     {
       f32x16 ac[4];
       gemm2_loop(ac, 1);
       mark(30);
-      __syncthreads();                                           // every wave is done reading the g image / X buffers
+      // no barrier here: the X buffers have been free since the gate's barrier, the g image is next written by the next
+      // tile's gate (eight barriers on), and the epilogue only touches this wave's own patch
+      tile_head();
       mark(31);
-      if (ntile < t_end) {
-        hrs = clip_rsrc(hin, b_nxt);
-        x_geom(t0_nxt, xvoff, xtok);
-        issue_x(hrs, xvoff, 0);
-      }
       __builtin_amdgcn_sched_barrier(0);
       epilogue(ac, pre1, srs, 1.0f, std::false_type{});
       mark(32);
@@ -643,7 +661,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   resblock_bf16p_kernel<D><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, \
                                                            b2_off, L, d, accumulate, ntiles, nblk)
 #ifdef AP_TOOLS
-  switch (g_dbg_bf16 & 0xfff) {
+  switch (g_dbg_bf16 & 0xefff) {
     case 0: AP_P_LAUNCH(0); break;
     case 1: AP_P_LAUNCH(1); break;
     case 2: AP_P_LAUNCH(2); break;
@@ -674,6 +692,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     case 2048: AP_P_LAUNCH(2048); break;
     case 2048 + 384: AP_P_LAUNCH(2048 + 384); break;
     case 1024 + 384: AP_P_LAUNCH(1024 + 384); break;
+    case 0x2000: AP_P_LAUNCH(0x2000); break;
     default: set_error("no such DBG instantiation"); return -22;
   }
 #else

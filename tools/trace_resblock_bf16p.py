@@ -24,7 +24,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = tr.cpu().numpy().reshape(G, 8, 64).astype(np.int64)
 names = {1: "pack chunk 0", 2: "barrier", 26: "gate (+ operand requests)", 27: "barrier", 28: "GEMM2 pass 0 k-loop", 29: "epilogue 0",
-         30: "GEMM2 pass 1 k-loop", 31: "barrier", 32: "next X request + epilogue 1"}
+         30: "GEMM2 pass 1 k-loop", 31: "next tile: X chunk 0 + weight requests", 32: "epilogue 1"}
 for ch in range(7):
     names[3 + ch * 3] = f"chunk {ch} heavy half"; names[4 + ch * 3] = f"chunk {ch} light half (+pack)"; names[5 + ch * 3] = f"chunk {ch} barrier"
 names[24] = "chunk 7 heavy half"; names[25] = "chunk 7 light half"
@@ -39,3 +39,12 @@ for i in range(1, 33):
     print(f"  {i:2d} {names[i]:34s} median {np.median(dseg):8.0f}   p10 {np.percentile(dseg, 10):8.0f}  p90 {np.percentile(dseg, 90):8.0f}")
 print("sums over the 8 chunks:", {k: int(sum(v)) for k, v in acc.items() if len(v) > 1})
 lib.ap_debug_bf16_dbg(0)
+# who is late: per workgroup the wave that arrives last at a chunk barrier waits ~0; the others wait for it
+bar = np.stack([t[:, :, 5 + ch * 3] - t[:, :, 4 + ch * 3] for ch in range(7)], 0)           # [chunk][wg][wave]
+arr = np.stack([t[:, :, 4 + ch * 3] - t[:, :, 2 + ch * 3] for ch in range(7)], 0)           # heavy + light, per wave
+print("chunk barriers: median over workgroups of the SHORTEST wait in the workgroup:", int(np.median(bar.min(2))))
+print("last wave to arrive (share of barriers):", np.round(np.bincount(bar.argmin(2).ravel(), minlength=8) / bar[:, :, 0].size, 2))
+print("median heavy+light per wave:", np.median(arr, (0, 1)).astype(int))
+print("median barrier wait per wave:", np.median(bar, (0, 1)).astype(int))
+rel = t[:, :, 4:25:3] - t[:, :1, 4:25:3]
+print("arrival at the chunk barrier relative to wave 0 (median per wave):", np.median(rel, (0, 2)).astype(int))
