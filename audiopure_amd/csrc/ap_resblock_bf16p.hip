@@ -249,14 +249,16 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   unsigned keep = xtok ? 0xffffffffu : 0u;
   bf16x8 a0[3][2];
   auto tile_head = [&]() {
-    issue_x(hrs, xvoff, 0);
 #pragma unroll
     for (int s = 0; s < 3; s++)
 #pragma unroll
       for (int rt = 0; rt < 2; rt++) a0[s][rt] = ld_w1(s * 2 + rt);
+    pack_all(lds, keep, 0);
+    issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's light half
   };
-  tile_head();
+  issue_x(hrs, xvoff, 0);
   __syncthreads();                                               // part_t, biases visible
+  tile_head();
 
   int tile_iter = 0;
   auto mark = [&](int i) {
@@ -298,8 +300,6 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         }
       }
     bf16x8 a1[3][2];
-    pack_all(lds, keep, 0);
-    issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's light half
     mark(1);
     __syncthreads();
     mark(2);
@@ -602,6 +602,8 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     hrs = clip_rsrc(hin, b_nxt);
     x_geom(t0_nxt, xvoff, xtok);
     keep = xtok ? 0xffffffffu : 0u;
+    issue_x(hrs, xvoff, 0);
+    __builtin_amdgcn_sched_barrier(0);
     {
       f32x16 ac[4];
       gemm2_loop(ac, 1);
