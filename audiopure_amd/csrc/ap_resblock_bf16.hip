@@ -683,7 +683,7 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
 #endif
   {
     const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
-    if (rc != 1) return rc;                                      // 1: shape not served there (d % 4, L % 4) -> per-tile kernel
+    if (rc != 1) return rc;                                      // 1: shape not served there (L % 4, C, S) -> per-tile kernel
   }
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const int ntiles = (L + BT - 1) / BT;

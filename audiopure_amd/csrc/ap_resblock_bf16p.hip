@@ -77,7 +77,7 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // DBG (tools builds only; outputs wrong by construction): 1 no weight loads in GEMM1's loop, 2 no X loads, 4 no pack,
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
 // 256 no stores, 512 no per-chunk barrier, 1024 every tile stages clip 0, 2048 phase stamps, 0x2000 no priority swap.
-template <int DBG>
+template <int DBG, bool UA = false>
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
@@ -147,10 +147,26 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     b = __builtin_amdgcn_readfirstlane(tile / ntiles);
     t0 = __builtin_amdgcn_readfirstlane((tile % ntiles) * PT_);
   };
-  auto x_geom = [&](int t0, unsigned &voff, bool &tok) {
+  // zero padding (WaveNet.py:26-27) as an AND mask on the packed values.  d % 4 == 0: a column quad is inside the clip or
+  // outside it as a whole, the address is clamped.  UA (d = 1, 2): unaligned 16-byte loads, one mask per sample; a sample
+  // after a row's end reads the next row (beyond the clip: the descriptor returns 0) and is masked.  Before the clip's
+  // first sample there is no address to give (buffer offsets are unsigned, and a 16-byte load that starts out of range
+  // returns zeros for all four dwords): those lanes -- column quad 0 of the -d tap in a clip's first tile -- load samples
+  // 0..3 and move them up by d registers before the pack (fix_x; wave-uniform test, one tile in ntiles).
+  struct Keep { unsigned m[UA ? 4 : 1]; bool fix, neg; };
+  Keep keep;
+  auto x_geom = [&](int t0, unsigned &voff, Keep &k) {
     const int tp = t0 + 4 * cg + (xtap - 1) * d;
-    tok = (tp >= 0) && (tp < L);
-    voff = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+    if constexpr (UA) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) k.m[i] = (tp + i >= 0 && tp + i < L) ? 0xffffffffu : 0u;
+      k.neg = tp < 0;
+      k.fix = (t0 == 0) && (xtap == 0);
+      voff = (unsigned)(max(tp, 0) + oct * 8 * L) * 4u;
+    } else {
+      k.m[0] = (tp >= 0 && tp < L) ? 0xffffffffu : 0u;
+      voff = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+    }
   };
   const __amdgpu_buffer_rsrc_t hrs_clip0 = clip_rsrc(hin, 0);
   auto issue_x = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch) {
@@ -185,7 +201,21 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   };
   float ptv8[8];
   u32x4 pkq;
+  auto fix_x = [&]() {
+    if constexpr (UA) {
+      if (keep.fix) {                                           // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+#pragma unroll
+          for (int i = 3; i >= 1; i--) {
+            const float lo = xr[e * 4 + (i >= 2 ? i - 2 : 0)], mid = xr[e * 4 + i - 1];
+            xr[e * 4 + i] = keep.neg ? (d == 2 ? lo : mid) : xr[e * 4 + i];
+          }
+      }
+    }
+  };
   auto pack_ptv = [&](int ch) {
+    fix_x();
     const float4 p0 = *reinterpret_cast<const float4 *>(ptx + ch * KC_);
     const float4 p1 = *reinterpret_cast<const float4 *>(ptx + ch * KC_ + 4);
     ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
@@ -193,17 +223,17 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   };
   // one eighth of a chunk's staging: sample i, channel pairs 2hf, 2hf+1 -> 4 adds, 2 cvt_pk, 2 and; the ds_write_b128 follows
   // a sample's second piece.  FiLM add (WaveNet.py:84), zero padding (:26-27) as an AND with the in-range mask.
-  auto pack_piece = [&](unsigned char *dst, unsigned keep, auto i_tag, auto hf_tag) {
+  auto pack_piece = [&](unsigned char *dst, const Keep &keep, auto i_tag, auto hf_tag) {
     constexpr int i = decltype(i_tag)::value, hf = decltype(hf_tag)::value;
     if constexpr (DBG & 4) return;
 #pragma unroll
     for (int e2 = 2 * hf; e2 < 2 * hf + 2; e2++)
       pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
                                                  f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
-                                                       xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep;
+                                                       xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep.m[UA ? i : 0];
     if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS_ + xk) * 2) = pkq;
   };
-  auto pack_all = [&](unsigned char *dst, unsigned keep, int ch) {
+  auto pack_all = [&](unsigned char *dst, const Keep &keep, int ch) {
     pack_ptv(ch);
     pack_piece(dst, keep, I0{}, I0{}); pack_piece(dst, keep, I0{}, I1{});
     pack_piece(dst, keep, I1{}, I0{}); pack_piece(dst, keep, I1{}, I1{});
@@ -241,12 +271,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   tile_bt(t_first, b_cur, t0_cur);
   __amdgpu_buffer_rsrc_t hrs = clip_rsrc(hin, b_cur);
   unsigned xvoff;
-  bool xtok;
-  x_geom(t0_cur, xvoff, xtok);
+  x_geom(t0_cur, xvoff, keep);
   // a tile's first X chunk and first weight fragments are requested at the END of the previous tile, ahead of that tile's
   // last stores (here for the first tile): a request issued after a store cannot be waited for without waiting for the
   // store (vmcnt retires in order)
-  unsigned keep = xtok ? 0xffffffffu : 0u;
   bf16x8 a0[3][2];
   auto tile_head = [&]() {
 #pragma unroll
@@ -600,8 +628,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     // (unconditional from here: after its last tile a workgroup re-requests that tile's first chunk and drops it -- a
     // conditional request would keep the staging and fragment registers live across the whole tile)
     hrs = clip_rsrc(hin, b_nxt);
-    x_geom(t0_nxt, xvoff, xtok);
-    keep = xtok ? 0xffffffffu : 0u;
+    x_geom(t0_nxt, xvoff, keep);
     issue_x(hrs, xvoff, 0);
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -636,7 +663,8 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
                           int B, int L, hipStream_t st) {
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
-  if (C != 256 || S != 256 || (L % 4) != 0 || L < 4 || (d % 4) != 0) return 1;
+  if (C != 256 || S != 256 || (L % 4) != 0 || L < 4) return 1;
+  const bool ua = (d % 4) != 0;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, n = 0;
@@ -663,6 +691,10 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   resblock_bf16p_kernel<D><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, \
                                                            b2_off, L, d, accumulate, ntiles, nblk)
 #ifdef AP_TOOLS
+  if (ua) {
+    resblock_bf16p_kernel<0, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off,
+                                                               b2_off, L, d, accumulate, ntiles, nblk);
+  } else
   switch (g_dbg_bf16 & 0xefff) {
     case 0: AP_P_LAUNCH(0); break;
     case 1: AP_P_LAUNCH(1); break;
@@ -698,7 +730,9 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     default: set_error("no such DBG instantiation"); return -22;
   }
 #else
-  AP_P_LAUNCH(0);
+  if (ua) resblock_bf16p_kernel<0, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,
+                                                                     b1_off, b2_off, L, d, accumulate, ntiles, nblk);
+  else AP_P_LAUNCH(0);
 #endif
 #undef AP_P_LAUNCH
   AP_HIP(hipGetLastError());

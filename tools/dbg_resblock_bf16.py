@@ -28,5 +28,5 @@ def t(layer, reps=5):
 for rnd in range(2):
     for v in variants:
         lib.ap_debug_bf16_dbg(v)
-        print(f"round {rnd} dbg {v:2d}: layer 5 (d=32) {t(5):7.3f} ms   layer 9 (d=512) {t(9):7.3f} ms", flush=True)
+        print(f"round {rnd} dbg {v:2d}: layer 0 (d=1) {t(0):7.3f} ms   layer 1 (d=2) {t(1):7.3f} ms   layer 5 (d=32) {t(5):7.3f} ms   layer 9 (d=512) {t(9):7.3f} ms", flush=True)
 lib.ap_debug_bf16_dbg(0)
