@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // cg&3, oct, cg>>2 so a load covers whole 64-B runs per channel row.  Waves 6, 7 repeat tap 2.
   const int xtap = min(wave >> 1, 2);
   const int cg = ((wave & 1) * 4 + (lane >> 4)) * 4 + (lane & 3), oct = (lane >> 2) & 3;
-  const int xcol = 4 * cg, xk = xtap * KC_ + oct * 8;
+  const int xcol = 4 * cg, xk = (xtap * KC_ + oct * 8) ^ ((__builtin_popcount(cg & 7) & 1) << 4);   // ^: the X image's 32-byte swizzle (below)
   const float *ptx = reinterpret_cast<const float *>(lds + PTOFF) + oct * 8;
 
   if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
@@ -261,7 +261,15 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   auto ld_w2 = [&](int gks) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, w2_off + (wave * 2 * NKS + gks) * 1024, 0));
   };
+  // X image swizzle: columns whose bits 2..4 have odd parity keep the two 32-byte halves of every 64 bytes of k swapped
+  // (k-step s of such a column sits where k-step s ^ 1 would).  A ds_write_b128 is served in groups of 8 consecutive lanes
+  // = column quads cg..cg+3 x 2 octets; the 832-byte quad stride puts quads cg and cg+2 on the same banks (2-way); with
+  // the swap the four quads of a group have parities 0,1,1,0 and land on four different bank octets.  The 16-lane groups
+  // of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}: MI355X_MICROARCH.md, LDS) each hold rows of ONE parity, so the
+  // reads stay the conflict-free permutation they were (a swap keyed on a single column bit made them 2-way: measured).
+  // Cost: one VGPR (a base for even and one for odd k-steps).
   const int rdoff = (j * XS_ + 8 * hh) * 2;                     // this lane's B-fragment byte offset inside an X buffer
+  const int rdsw = (__builtin_popcount((j >> 2) & 7) & 1) * 32;
   const unsigned char *gb = lds + GOFF + (j * GS_ + 8 * hh) * 2;
   float *patch = reinterpret_cast<float *>(lds + POFF) + wave * 32 * PS_;
   const float RS = 0.707106781186547524f;
@@ -339,14 +347,14 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[rt][ct], 0, 0, 0);
       }
     };
-    auto rdb = [&](bf16x8 &dst, const unsigned char *xb, int ct, int s) {
+    auto rdb = [&](bf16x8 &dst, const unsigned char *xbe, const unsigned char *xbo, int ct, int ks) {   // ks: k-step 0..5 of the chunk
       if constexpr (DBG & 16) asm volatile("" : "=v"(dst));
-      else dst = *reinterpret_cast<const bf16x8 *>(xb + (32 * ct) * (XS_ * 2) + s * 32);
+      else dst = *reinterpret_cast<const bf16x8 *>(((ks & 1) ? xbo : xbe) + (32 * ct) * (XS_ * 2) + ks * 32);
     };
     // heavy half: k-steps 0-2 of the chunk on fragment set `use`; requests set `nxt` (6 loads) and the next chunk's X rows
     // (8 loads), one between each of the first MFMAs (the CU's memory pipe takes a wave-wide load every ~16 cycles)
-    auto half_heavy = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], int nfrag, int xch,
-                          bool with_x) {
+    auto half_heavy = [&](const bf16x8(&use)[3][2], const unsigned char *xbe, const unsigned char *xbo, bf16x8(&nxt)[3][2],
+                          int nfrag, int xch, bool with_x) {
       // the two waves of a SIMD: the older one (waves 0-3) wins every issue conflict and reached the chunk barrier ~1.2 k
       // cycles ahead of the younger one, which then finished alone with its stalls exposed (tools/trace_resblock_bf16p.py).
       // The younger wave gets the priority in this half, the older one (by age) in the other half: -1.3 % block time.
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       for (int s = 0; s < 3; s++) {
         bf16x8 bv[4];
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xb, ct, s);
+        for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xbe, xbo, ct, s);
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -403,13 +411,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     // light half, explicit order (pinned with sched_barrier): column-tile-major MFMA pairs share one B fragment, which is
     // re-read for the next k-step right after its pair (6 MFMAs = its latency ahead of the next use).  Fillers: the next
     // set's six weight fragments in k-step 0, then the eight staging pieces of the next chunk.
-    auto half_light = [&](const bf16x8(&use)[3][2], const unsigned char *xb, bf16x8(&nxt)[3][2], int nfrag,
-                          unsigned char *pdst, int pch, auto last_tag) {
+    auto half_light = [&](const bf16x8(&use)[3][2], const unsigned char *xbe, const unsigned char *xbo, bf16x8(&nxt)[3][2],
+                          int nfrag, unsigned char *pdst, int pch, auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
       if constexpr (!(DBG & 0x2000)) __builtin_amdgcn_s_setprio(0);
       bf16x8 bv[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xb, ct, 0);
+      for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xbe, xbo, ct, 3);
       if constexpr (!LAST) pack_ptv(pch);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           }
           __builtin_amdgcn_sched_barrier(0);
           mf(use[s][1], bv[ct], 1, ct);
-          if (s < 2) rdb(bv[ct], xb, ct, s + 1);
+          if (s < 2) rdb(bv[ct], xbe, xbo, ct, 3 + s + 1);
           if constexpr (!LAST) {
             // the staging registers are free again: request the chunk after next right away (its pack is one chunk away)
             if (s == 2 && ct == 0 && pch + 1 < NCH) issue_x(hrs, xvoff, pch + 1);
@@ -445,19 +453,19 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 
 #pragma unroll 1
     for (int ch = 0; ch < NCH - 1; ch++) {
-      const unsigned char *xb = lds + (ch & 1) * XBYTES + rdoff;
-      half_heavy(a0, xb, a1, ch * 12 + 6, ch + 1, true);
+      const unsigned char *xbe = lds + (ch & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
+      half_heavy(a0, xbe, xbo, a1, ch * 12 + 6, ch + 1, true);
       mark(3 + ch * 3);
-      half_light(a1, xb + 3 * 32, a0, (ch + 1) * 12, lds + ((ch + 1) & 1) * XBYTES, ch + 1, std::false_type{});
+      half_light(a1, xbe, xbo, a0, (ch + 1) * 12, lds + ((ch + 1) & 1) * XBYTES, ch + 1, std::false_type{});
       mark(4 + ch * 3);
       if constexpr (!(DBG & 512)) __syncthreads();              // DBG 512 (timing only): no per-chunk barrier
       mark(5 + ch * 3);
     }
     {
-      const unsigned char *xb = lds + ((NCH - 1) & 1) * XBYTES + rdoff;
-      half_heavy(a0, xb, a1, (NCH - 1) * 12 + 6, 0, false);
+      const unsigned char *xbe = lds + ((NCH - 1) & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
+      half_heavy(a0, xbe, xbo, a1, (NCH - 1) * 12 + 6, 0, false);
       mark(24);
-      half_light(a1, xb + 3 * 32, a0, 0, nullptr, 0, std::true_type{});
+      half_light(a1, xbe, xbo, a0, 0, nullptr, 0, std::true_type{});
       mark(25);
     }
 
