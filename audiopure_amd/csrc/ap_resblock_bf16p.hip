@@ -14,8 +14,11 @@
 //   - the first X chunk of the NEXT tile is requested before the last epilogue's stores, so the stores of a tile drain
 //     behind the next tile's GEMM1 and no wait ever names them (vmcnt retires in order: a load issued after a store could
 //     not be waited for without waiting for the store);
-//   - the next chunk's FiLM add / bf16 pack / ds_write sit between the MFMAs of a chunk's second half (two X buffers
-//     instead of three), so the chunk has no VALU-only tail.
+//   - the next chunk's FiLM add / bf16 pack / ds_write sit between the MFMAs of a chunk's fourth k-step (two X buffers
+//     instead of three), so the chunk has no VALU-only tail;
+//   - no register is spilled: a scratch reload inside the tile loop is a vector-memory load whose wait (vmcnt(0)) drains
+//     every request in flight.  Lane geometry that is needed once per chunk / tile is re-derived from the lane id there
+//     instead of being kept (x_geom, pack_ptv), the GEMM1 fragments are a ring of three k-steps (24 registers).
 // Layout notes: X image [column][k] bf16, 208-B rows (conflict-free ds_read_b128 B fragments); g image [column][channel],
 // 528-B rows; wave-private 32 x 32 fp32 output patch with 128-B rows (with the 16-lane groups of ds_read_b128 a padded
 // 144-B row was 2-way conflicted, the unpadded one is conflict-free for both the column writes and the row reads).
@@ -76,7 +79,7 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 
 // DBG (tools builds only; outputs wrong by construction): 1 no weight loads in GEMM1's loop, 2 no X loads, 4 no pack,
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
-// 256 no stores, 512 no per-chunk barrier, 1024 every tile stages clip 0, 2048 phase stamps, 0x2000 no priority swap.
+// 256 no stores, 512 no per-chunk barrier, 1024 every tile stages the same 128 columns of clip 0, 2048 phase stamps, 0x2000 no priority swap.
 template <int DBG, bool UA = false>
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
@@ -131,7 +134,6 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   const int xtap = min(wave >> 1, 2);
   const int cg = ((wave & 1) * 4 + (lane >> 4)) * 4 + (lane & 3), oct = (lane >> 2) & 3;
   const int xcol = 4 * cg, xk = (xtap * KC_ + oct * 8) ^ ((__builtin_popcount(cg & 7) & 1) << 4);   // ^: the X image's 32-byte swizzle (below)
-  const float *ptx = reinterpret_cast<const float *>(lds + PTOFF) + oct * 8;
 
   if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
   // the bias vectors live in LDS for the whole kernel: fetched per tile from memory they sat behind the previous tile's
@@ -155,7 +157,14 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // 0..3 and move them up by d registers before the pack (fix_x; wave-uniform test, one tile in ntiles).
   struct Keep { unsigned m[UA ? 4 : 1]; bool fix, neg; };
   Keep keep;
-  auto x_geom = [&](int t0, unsigned &voff, Keep &k) {
+  auto x_geom = [&](int t0_in, unsigned &voff, Keep &k) {
+    const int t0 = (DBG & 1024) ? 8192 : t0_in;                  // timing-only: every tile stages the same 128 columns of clip 0
+    // the lane's column quad and channel octet are re-derived from a lane id read here (volatile asm: not hoisted out of the
+    // tile loop): kept from the prologue they were spilled, and a scratch reload waits with vmcnt(0) -- here, behind the
+    // first epilogue's stores
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int cg = ((wave & 1) * 4 + (ln >> 4)) * 4 + (ln & 3), oct = (ln >> 2) & 3;
     const int tp = t0 + 4 * cg + (xtap - 1) * d;
     if constexpr (UA) {
 #pragma unroll
@@ -169,35 +178,17 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     }
   };
   const __amdgpu_buffer_rsrc_t hrs_clip0 = clip_rsrc(hin, 0);
-  auto issue_x = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch) {
+  auto issue_x1 = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch, int e) {       // channel e of chunk ch
     if constexpr (DBG & 2) return;
     const __amdgpu_buffer_rsrc_t &rs = (DBG & 1024) ? hrs_clip0 : rs_in;      // timing-only: every tile stages clip 0 (cache-resident X)
+    // (bit_cast the whole vector: element-wise bit_cast of the builtin's int vector is mis-folded to a splat)
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (ch * KC_ + e) * L * 4, 0));
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      // (bit_cast the whole vector: element-wise bit_cast of the builtin's int vector is mis-folded to a splat)
-      const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (ch * KC_ + e) * L * 4, 0));
+    for (int i = 0; i < 4; i++) xr[e * 4 + i] = v[i];
+  };
+  auto issue_x = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) xr[e * 4 + i] = v[i];
-    }
-  };
-  // ---- software prefetch into L2: one dword per 128-B line, two chunks (and the read-modify-write operands a few
-  // microseconds) ahead of the wide loads that use the data.  A wide load issued one chunk ahead of its use does not
-  // cover an HBM miss under load (the ablation without X loads was 26 % faster), and deeper register staging does not fit;
-  // the sparse loads cost one VGPR and ~1 instruction per wave and chunk, and turn the later loads into L2 hits.
-  const int pf_tap = tid >> 7, pf_c = (tid & 127) >> 2, pf_ln = tid & 3;    // threads 0..383: (tap, channel, line of the row)
-  auto prefetch_x = [&](const __amdgpu_buffer_rsrc_t &rs, int t0p, int ch) -> unsigned {
-    if constexpr (!(DBG & 2048)) return 0u;
-    unsigned v = 0;
-    if (tid < 384) {                                            // waves 6, 7 sit out (wave-uniform)
-      const int tp = min(max(t0p + (pf_tap - 1) * d + pf_ln * 32, 0), L - 1);
-      v = __builtin_amdgcn_raw_buffer_load_b32(rs, ((unsigned)(ch * KC_ + pf_c) * (unsigned)L + (unsigned)tp) * 4u, 0, 0);
-    }
-    return v;
-  };
-  auto prefetch_rows = [&](const __amdgpu_buffer_rsrc_t &rs, int t0p, int half) -> unsigned {   // 256 rows x 4 lines, 2 halves
-    if constexpr (!(DBG & 2048)) return 0u;
-    const int row = half * 128 + (tid >> 2), tp = min(t0p + (tid & 3) * 32, L - 1);
-    return __builtin_amdgcn_raw_buffer_load_b32(rs, ((unsigned)row * (unsigned)L + (unsigned)tp) * 4u, 0, 0);
+    for (int e = 0; e < 8; e++) issue_x1(rs_in, voff, ch, e);
   };
   float ptv8[8];
   u32x4 pkq;
@@ -216,8 +207,11 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   };
   auto pack_ptv = [&](int ch) {
     fix_x();
-    const float4 p0 = *reinterpret_cast<const float4 *>(ptx + ch * KC_);
-    const float4 p1 = *reinterpret_cast<const float4 *>(ptx + ch * KC_ + 4);
+    int ln;                                                     // (lane id read here, not kept: see x_geom)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const float *ptc = reinterpret_cast<const float *>(lds + PTOFF) + ((ln >> 2) & 3) * 8 + ch * KC_;
+    const float4 p0 = *reinterpret_cast<const float4 *>(ptc);
+    const float4 p1 = *reinterpret_cast<const float4 *>(ptc + 4);
     ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
     ptv8[4] = p1.x; ptv8[5] = p1.y; ptv8[6] = p1.z; ptv8[7] = p1.w;
   };
@@ -283,14 +277,16 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // a tile's first X chunk and first weight fragments are requested at the END of the previous tile, ahead of that tile's
   // last stores (here for the first tile): a request issued after a store cannot be waited for without waiting for the
   // store (vmcnt retires in order)
-  bf16x8 a0[3][2];
+  constexpr int RING = 3, PK = 3;                                // fragment ring depth (k-steps), k-step that carries the pack (a ring of
+                                                                 // six with the pack in k-step 5 -- a chunk of lead for X -- measured +2 %)
+  bf16x8 w[RING][2];                                                // GEMM1 fragment ring: k-step ks of a chunk uses w[ks % RING][row tile]
   auto tile_head = [&]() {
 #pragma unroll
-    for (int s = 0; s < 3; s++)
+    for (int ks = 0; ks < RING; ks++)
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++) a0[s][rt] = ld_w1(s * 2 + rt);
+      for (int rt = 0; rt < 2; rt++) w[ks][rt] = ld_w1(ks * 2 + rt);
     pack_all(lds, keep, 0);
-    issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's light half
+    issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's fourth k-step
   };
   issue_x(hrs, xvoff, 0);
   __syncthreads();                                               // part_t, biases visible
@@ -315,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     }
 #endif
   };
+  auto mark_half = [&](int ch) { mark(ch < NCH - 1 ? 3 + ch * 3 : 24); };
 #pragma unroll 1
   for (int tile = t_first; tile < t_end; tile += t_step, tile_iter++) {
     mark(0);
@@ -328,14 +325,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       for (int q = 0; q < 4; q++) {
         const f32x4 bv4 = *reinterpret_cast<const f32x4 *>(lds + BOFF + (rt * C + 32 * wave + 8 * q + 4 * hh) * 4);
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) {
-          acc[rt][ct][4 * q + 0] = bv4[0];
+        for (int ct = 0; ct < 4; ct++) {                        // (128 v_mov per wave and tile: entering the bias as the C operand of
+          acc[rt][ct][4 * q + 0] = bv4[0];                      //  each tile's first MFMA instead measured the same -- hidden work)
           acc[rt][ct][4 * q + 1] = bv4[1];
           acc[rt][ct][4 * q + 2] = bv4[2];
           acc[rt][ct][4 * q + 3] = bv4[3];
         }
       }
-    bf16x8 a1[3][2];
     mark(1);
     __syncthreads();
     mark(2);
@@ -351,49 +347,17 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       if constexpr (DBG & 16) asm volatile("" : "=v"(dst));
       else dst = *reinterpret_cast<const bf16x8 *>(((ks & 1) ? xbo : xbe) + (32 * ct) * (XS_ * 2) + ks * 32);
     };
-    // heavy half: k-steps 0-2 of the chunk on fragment set `use`; requests set `nxt` (6 loads) and the next chunk's X rows
-    // (8 loads), one between each of the first MFMAs (the CU's memory pipe takes a wave-wide load every ~16 cycles)
-    auto half_heavy = [&](const bf16x8(&use)[3][2], const unsigned char *xbe, const unsigned char *xbo, bf16x8(&nxt)[3][2],
-                          int nfrag, int xch, bool with_x) {
-      // the two waves of a SIMD: the older one (waves 0-3) wins every issue conflict and reached the chunk barrier ~1.2 k
-      // cycles ahead of the younger one, which then finished alone with its stalls exposed (tools/trace_resblock_bf16p.py).
-      // The younger wave gets the priority in this half, the older one (by age) in the other half: -1.3 % block time.
-      if constexpr (!(DBG & 0x2000)) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
-      if constexpr (!(DBG & 1)) {
-#pragma unroll
-        for (int s = 0; s < 3; s++)
-#pragma unroll
-          for (int rt = 0; rt < 2; rt++) nxt[s][rt] = ld_w1(nfrag + s * 2 + rt);
-      }
-      (void)xch; (void)with_x;
-#pragma unroll
-      for (int s = 0; s < 3; s++) {
-        bf16x8 bv[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xbe, xbo, ct, s);
-#pragma unroll
-        for (int rt = 0; rt < 2; rt++)
-#pragma unroll
-          for (int ct = 0; ct < 4; ct++) mf(use[s][rt], bv[ct], rt, ct);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-      for (int i = 0; i < 24; i++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if ((i & 7) >= 3 && (i & 7) <= 6 && i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // light half: k-steps 3-5 in explicit order; fillers = the next set's weight fragments, the B fragments one k-step
-    // ahead, then (PACK) the eight staging pieces of the next chunk or (PRE) the 16 loads of the residual's h patch
     float pre[4][16];
-    unsigned evoff[4];
+    unsigned evoff[4];                                          // E4 mapping: lane = (row lane>>3 (+8 per step), column quad lane&7)
+    auto calc_evoff = [&]() {                                   // called after GEMM1 (t0 made opaque there: computed before the
+      int t0o = t0;                                             // chunk loop the four offsets sat in registers through GEMM1)
+      asm volatile("" : "+s"(t0o));
 #pragma unroll
-    for (int ct = 0; ct < 4; ct++) {                            // E4 mapping: lane = (row lane>>3 (+8 per step), column quad lane&7)
-      const int t = t0 + 32 * ct + 4 * (lane & 7);
-      evoff[ct] = t < L ? ((unsigned)(32 * wave + (lane >> 3)) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
-    }                                                           // 0x80000000: outside the clip -> loads 0, store dropped
+      for (int ct = 0; ct < 4; ct++) {
+        const int t = t0o + 32 * ct + 4 * (lane & 7);
+        evoff[ct] = t < L ? ((unsigned)(32 * wave + (lane >> 3)) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
+      }                                                         // 0x80000000: outside the clip -> loads 0, store dropped
+    };
     auto load_pre = [&](const __amdgpu_buffer_rsrc_t &rs, auto ct_tag) {
       constexpr int ct = decltype(ct_tag)::value;
       if constexpr (DBG & 128) {
@@ -408,43 +372,61 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         }
       }
     };
-    // light half, explicit order (pinned with sched_barrier): column-tile-major MFMA pairs share one B fragment, which is
-    // re-read for the next k-step right after its pair (6 MFMAs = its latency ahead of the next use).  Fillers: the next
-    // set's six weight fragments in k-step 0, then the eight staging pieces of the next chunk.
-    auto half_light = [&](const bf16x8(&use)[3][2], const unsigned char *xbe, const unsigned char *xbo, bf16x8(&nxt)[3][2],
-                          int nfrag, unsigned char *pdst, int pch, auto last_tag) {
-      constexpr bool LAST = decltype(last_tag)::value;
-      if constexpr (!(DBG & 0x2000)) __builtin_amdgcn_s_setprio(0);
+    // One chunk = six k-steps of eight MFMAs in explicit order (pinned with sched_barrier): column-tile-major pairs share one
+    // B fragment, which is re-read for the next k-step right after its pair.  Global requests of a chunk and wave:
+    //   * a k-step's two weight fragments are replaced right behind their last MFMA by those of the k-step three on (a ring
+    //     of three k-steps, 24 registers: two k-steps = 16 MFMAs of lead, as the two half-chunk sets had at their tightest);
+    //   * k-step 3: FiLM add / bf16 pack / ds_write of the next chunk (eight pieces, one per MFMA gap);
+    //   * behind the last MFMA: the X rows of the chunk after next (the staging registers are free from the pack on, but
+    //     every weight request issued before the next pack has to be OLDER than the X request -- vmcnt retires in order, so
+    //     a wait for a younger fragment would be a wait for the X rows).
+    // No spilled value may be reloaded inside the tile loop: a scratch reload is a vector-memory load, its wait is
+    // s_waitcnt vmcnt(0), and that drains every request in flight (the round's earlier builds had one per chunk).
+    // The two waves of a SIMD: the older one (waves 0-3) wins every issue conflict and reached the chunk barrier ~1.2 k cycles
+    // ahead of the younger one, which then finished alone with its stalls exposed (tools/trace_resblock_bf16p.py): the
+    // younger wave gets the priority in k-steps 0-2, the older one (by age) in 3-5.
+    auto chunk = [&](const unsigned char *xbe, const unsigned char *xbo, int ch, unsigned char *pdst, auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;            // 0: chunks 0..NCH-3, 1: NCH-2 (no X request), 2: NCH-1
+      constexpr bool LAST = KIND == 2, WITH_X = KIND == 0;
       bf16x8 bv[4];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xbe, xbo, ct, 3);
-      if constexpr (!LAST) pack_ptv(pch);
+      for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xbe, xbo, ct, 0);
+      if constexpr (!(DBG & 0x2000)) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 3; s++) {
+      for (int ks = 0; ks < 6; ks++) {
+        const bool reload = !(DBG & 1) && (ks + RING < 6 || !LAST);     // (ring 3) k-steps 3-5 fetch the next chunk's first three
+        const int nfrag = ks + RING < 6 ? ch * 12 + (ks + RING) * 2 : (ch + 1) * 12 + (ks + RING - 6) * 2;
+        if (ks == 3) {
+          if constexpr (!(DBG & 0x2000)) __builtin_amdgcn_s_setprio(0);
+          mark_half(ch);
+        }
+        if (ks == PK) {
+          if constexpr (!LAST) pack_ptv(ch + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) {
-          mf(use[s][0], bv[ct], 0, ct);
+          mf(w[ks % RING][0], bv[ct], 0, ct);
           if constexpr (!LAST) {
-            if (s == 0 && !(DBG & 1)) nxt[ct >> 1][ct & 1] = ld_w1(nfrag + ct);
-            if (s == 1 && ct == 0) pack_piece(pdst, keep, I0{}, I0{});
-            if (s == 1 && ct == 1) pack_piece(pdst, keep, I1{}, I0{});
-            if (s == 1 && ct == 2) pack_piece(pdst, keep, I2{}, I0{});
-            if (s == 1 && ct == 3) pack_piece(pdst, keep, I3{}, I0{});
+            if (ks == PK && ct == 0) pack_piece(pdst, keep, I0{}, I0{});
+            if (ks == PK && ct == 1) pack_piece(pdst, keep, I1{}, I0{});
+            if (ks == PK && ct == 2) pack_piece(pdst, keep, I2{}, I0{});
+            if (ks == PK && ct == 3) pack_piece(pdst, keep, I3{}, I0{});
           }
+          if (ct == 3 && reload) w[ks % RING][0] = ld_w1(nfrag);
           __builtin_amdgcn_sched_barrier(0);
-          mf(use[s][1], bv[ct], 1, ct);
-          if (s < 2) rdb(bv[ct], xbe, xbo, ct, 3 + s + 1);
+          mf(w[ks % RING][1], bv[ct], 1, ct);
+          if (ks < 5) rdb(bv[ct], xbe, xbo, ct, ks + 1);
           if constexpr (!LAST) {
-            // the staging registers are free again: request the chunk after next right away (its pack is one chunk away)
-            if (s == 2 && ct == 0 && pch + 1 < NCH) issue_x(hrs, xvoff, pch + 1);
+            if (ks == PK && ct == 0) pack_piece(pdst, keep, I0{}, I1{});
+            if (ks == PK && ct == 1) pack_piece(pdst, keep, I1{}, I1{});
+            if (ks == PK && ct == 2) pack_piece(pdst, keep, I2{}, I1{});
+            if (ks == PK && ct == 3) pack_piece(pdst, keep, I3{}, I1{});
           }
-          if constexpr (!LAST) {
-            if (s == 0 && ct < 2 && !(DBG & 1)) nxt[2][ct] = ld_w1(nfrag + 4 + ct);
-            if (s == 1 && ct == 0) pack_piece(pdst, keep, I0{}, I1{});
-            if (s == 1 && ct == 1) pack_piece(pdst, keep, I1{}, I1{});
-            if (s == 1 && ct == 2) pack_piece(pdst, keep, I2{}, I1{});
-            if (s == 1 && ct == 3) pack_piece(pdst, keep, I3{}, I1{});
+          if (ct == 3 && reload) w[ks % RING][1] = ld_w1(nfrag + 1);
+          if constexpr (WITH_X) {
+            if (ks == 5 && ct == 3) issue_x(hrs, xvoff, ch + 2);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -452,20 +434,23 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     };
 
 #pragma unroll 1
-    for (int ch = 0; ch < NCH - 1; ch++) {
+    for (int ch = 0; ch < NCH - 2; ch++) {
       const unsigned char *xbe = lds + (ch & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
-      half_heavy(a0, xbe, xbo, a1, ch * 12 + 6, ch + 1, true);
-      mark(3 + ch * 3);
-      half_light(a1, xbe, xbo, a0, (ch + 1) * 12, lds + ((ch + 1) & 1) * XBYTES, ch + 1, std::false_type{});
+      chunk(xbe, xbo, ch, lds + ((ch + 1) & 1) * XBYTES, I0{});
       mark(4 + ch * 3);
       if constexpr (!(DBG & 512)) __syncthreads();              // DBG 512 (timing only): no per-chunk barrier
       mark(5 + ch * 3);
     }
     {
+      const unsigned char *xbe = lds + ((NCH - 2) & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
+      chunk(xbe, xbo, NCH - 2, lds + ((NCH - 1) & 1) * XBYTES, I1{});
+      mark(4 + (NCH - 2) * 3);
+      if constexpr (!(DBG & 512)) __syncthreads();
+      mark(5 + (NCH - 2) * 3);
+    }
+    {
       const unsigned char *xbe = lds + ((NCH - 1) & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
-      half_heavy(a0, xbe, xbo, a1, (NCH - 1) * 12 + 6, 0, false);
-      mark(24);
-      half_light(a1, xbe, xbo, a0, 0, nullptr, 0, std::true_type{});
+      chunk(xbe, xbo, NCH - 1, nullptr, I2{});
       mark(25);
     }
 
@@ -492,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         bias[q] = v;
       }
     };
+    calc_evoff();
     load_a4(p0, 0);
     load_pre(hrs, I0{});                                         // the residual's h patch, first half (what fits beside the accumulators)
     load_pre(hrs, I1{});
