@@ -27,12 +27,12 @@ __global__ __launch_bounds__(512, 2) void k(const float *src, unsigned bytes, fl
 }
 template <int ROWS> double run(const float *d, unsigned bytes, float *o, unsigned long long *c, int iters) {
   k<ROWS><<<256, 512>>>(d, bytes, o, 10, c);
-  hipDeviceSynchronize();
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipEventRecord(e0);
+  (void)hipDeviceSynchronize();
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0);
   k<ROWS><<<256, 512>>>(d, bytes, o, iters, c);
-  hipEventRecord(e1); hipEventSynchronize(e1);
-  float ms; hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   const double loads_per_cu = (double)iters * 8 * 8;                 // wave-instructions per CU
   printf("%2d rows x %4d B: %7.3f ms  -> %6.1f ns per wave-load per CU = %5.1f B/ns/CU (%.2f TB/s chip)\n", ROWS, 1024 / ROWS, ms,
          ms * 1e6 / loads_per_cu, 1024.0 / (ms * 1e6 / loads_per_cu), 256 * 1024.0 / (ms * 1e6 / loads_per_cu) / 1000);
@@ -41,7 +41,7 @@ template <int ROWS> double run(const float *d, unsigned bytes, float *o, unsigne
 int main() {
   const unsigned bytes = 16u * 64 * ROWB + 65536;                    // 16 x ROWS x 64 KB rows fit: 65 MB max, mostly L2/MALL resident rows
   float *d, *o; unsigned long long *c;
-  hipMalloc(&d, bytes); hipMemset(d, 0, bytes); hipMalloc(&o, 4096); hipMalloc(&c, 256 * 8);
+  (void)hipMalloc(&d, bytes); (void)hipMemset(d, 0, bytes); (void)hipMalloc(&o, 4096); (void)hipMalloc(&c, 256 * 8);
   for (int rep = 0; rep < 2; rep++) {
     run<1>(d, bytes, o, c, 2000); run<2>(d, bytes, o, c, 2000); run<4>(d, bytes, o, c, 2000); run<8>(d, bytes, o, c, 2000); run<16>(d, bytes, o, c, 2000);
   }

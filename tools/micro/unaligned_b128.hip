@@ -16,10 +16,10 @@ int main() {
   const int n = 1024;
   unsigned h[n], *d, *ob, *og, rb[256], rg[256];
   for (int i = 0; i < n; i++) h[i] = i;
-  hipMalloc(&d, n * 4); hipMalloc(&ob, 1024); hipMalloc(&og, 1024);
-  hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice);
+  (void)hipMalloc(&d, n * 4); (void)hipMalloc(&ob, 1024); (void)hipMalloc(&og, 1024);
+  (void)hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice);
   k<<<1, 64>>>(d, ob, og, n);
-  hipMemcpy(rb, ob, 1024, hipMemcpyDeviceToHost); hipMemcpy(rg, og, 1024, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(rb, ob, 1024, hipMemcpyDeviceToHost); (void)hipMemcpy(rg, og, 1024, hipMemcpyDeviceToHost);
   int badb = 0, badg = 0;
   for (int i = 0; i < 64; i++) for (int e = 0; e < 4; e++) { badb += rb[i * 4 + e] != (unsigned)(i + e); badg += rg[i * 4 + e] != (unsigned)(i + e); }
   printf("buffer_load_b128 unaligned: %s (%d wrong)   global_load_dwordx4 unaligned: %s (%d wrong)\n", badb ? "WRONG" : "ok", badb, badg ? "WRONG" : "ok", badg);
