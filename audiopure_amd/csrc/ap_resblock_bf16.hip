@@ -23,14 +23,13 @@ constexpr int XSTRIDE = 3 * BKC + 8;    // bf16 elements per column row of the X
 
 __device__ __forceinline__ int rowoff_b(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-// tanh(a) sigmoid(b) = (E-1)/((E+1)(1+F)); plain hardware exp2/rcp are ample next to bf16 operand rounding (2^-9)
-// Overflow-free form without clamps: with E = e^(-2|a|) in (0, 1], tanh(a) = sign(a) (1 - E) / (1 + E); F = e^(-b) may
-// overflow to +inf, then the denominator is +inf and the gate 0, which is the limit.
+// tanh(a) sigmoid(b) = (1 - E) / ((1 + E)(1 + F)), E = e^(-2a), F = e^(-b); plain hardware exp2 / rcp are ample next to bf16
+// operand rounding (2^-9).  a is clamped to [-16, 16] first (tanh(+-16) rounds to +-1 in fp32: no result changes), so E stays
+// finite and the sign comes out of 1 - E; F may overflow to +inf, then the denominator is +inf and the gate 0, the limit.
 __device__ __forceinline__ float gate_fast(float a, float b) {
-  const float E = __builtin_amdgcn_exp2f(__builtin_fabsf(a) * -2.885390081777926815f);
+  const float E = __builtin_amdgcn_exp2f(__builtin_amdgcn_fmed3f(a, -16.0f, 16.0f) * -2.885390081777926815f);
   const float F = __builtin_amdgcn_exp2f(b * -1.442695040888963407f);
-  const float g = (1.0f - E) * __builtin_amdgcn_rcpf((1.0f + E) * (1.0f + F));
-  return __builtin_copysignf(g, a);
+  return (1.0f - E) * __builtin_amdgcn_rcpf((1.0f + E) * (1.0f + F));
 }
 
 // ---- weight images -------------------------------------------------------------------------------------------

@@ -44,26 +44,22 @@ constexpr int PS_ = 32;                  // fp32 per row of the wave-private out
 
 __device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
-// tanh(a) sigmoid(b) with E = e^(-2|a|) in (0,1], F = e^(-b) (may overflow to +inf -> gate 0, the limit); no clamps
-__device__ __forceinline__ float gate_fast(float a, float b) {
-  const float E = __builtin_amdgcn_exp2f(__builtin_fabsf(a) * -2.885390081777926815f);
-  const float F = __builtin_amdgcn_exp2f(b * -1.442695040888963407f);
-  const float g = (1.0f - E) * __builtin_amdgcn_rcpf((1.0f + E) * (1.0f + F));
-  return __builtin_copysignf(g, a);
-}
-
-// the gate on a pair of values: the plain arithmetic as two-wide fp32 vector operations (v_pk_add_f32 / v_pk_mul_f32: one
-// issue slot for two gates; the file is built with -fno-slp-vectorize, so the pairing is written out), the three
-// transcendentals per gate stay scalar.  Same formula as gate_fast.
+// tanh(a) sigmoid(b) = (1 - E) / ((1 + E)(1 + F)), E = e^(-2a), F = e^(-b).  a is clamped to [-16, 16] first (one v_med3;
+// tanh(+-16) rounds to +-1 in fp32, so the clamp changes no result): E stays finite, the sign comes out of 1 - E, and no
+// abs / copysign pair is needed.  F may overflow to +inf: the denominator is +inf then and the gate 0, which is the limit.
+// The same arithmetic, element for element, as gate_fast of ap_resblock_bf16.hip (the two kernels are bit-identical).
+// On a pair of values: plain arithmetic as two-wide fp32 operations (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two
+// gates; the file is built with -fno-slp-vectorize, so the pairing is written out), the three transcendentals per gate
+// stay scalar; the caller converts the pair to bf16 with one v_cvt_pk_bf16_f32.
 __device__ __forceinline__ f32x2 gate_fast2(f32x2 a, f32x2 b) {
-  const f32x2 ea = f32x2{__builtin_fabsf(a[0]), __builtin_fabsf(a[1])} * -2.885390081777926815f;
+  const f32x2 ac = {__builtin_amdgcn_fmed3f(a[0], -16.0f, 16.0f), __builtin_amdgcn_fmed3f(a[1], -16.0f, 16.0f)};
+  const f32x2 ea = ac * -2.885390081777926815f;
   const f32x2 eb = b * -1.442695040888963407f;
   const f32x2 E = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
   const f32x2 F = {__builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
   const f32x2 den = (E + 1.0f) * (F + 1.0f);
   const f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-  const f32x2 g = (1.0f - E) * r;
-  return f32x2{__builtin_copysignf(g[0], a[0]), __builtin_copysignf(g[1], a[1])};
+  return (1.0f - E) * r;
 }
 
 using I0 = std::integral_constant<int, 0>;
@@ -465,6 +461,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     float4 bias[4];
     auto fetch_bias = [&](auto pass_tag) {
       constexpr int pass = decltype(pass_tag)::value;
+      int ln;                                                    // (lane id read here, not kept: see x_geom)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int hh = ln >> 5;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = 32 * wave + 8 * q + 4 * hh;
@@ -504,16 +503,15 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       constexpr int ct = decltype(ct_tag)::value;
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
-        bf16x4 pk;
+        unsigned pk[2];
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const f32x2 a2 = {acc[0][ct][4 * qq + e], acc[0][ct][4 * qq + e + 1]};
           const f32x2 b2 = {acc[1][ct][4 * qq + e], acc[1][ct][4 * qq + e + 1]};
           const f32x2 g2 = (DBG & 32) ? a2 + b2 : gate_fast2(a2, b2);
-          pk[e] = (__bf16)g2[0];
-          pk[e + 1] = (__bf16)g2[1];
+          pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(g2, bf16x2));
         }
-        *reinterpret_cast<bf16x4 *>(lds + GOFF + ((32 * ct + j) * GS_ + 32 * wave + 8 * qq + 4 * hh) * 2) = pk;
+        *reinterpret_cast<uint2 *>(lds + GOFF + ((32 * ct + j) * GS_ + 32 * wave + 8 * qq + 4 * hh) * 2) = make_uint2(pk[0], pk[1]);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
