@@ -719,6 +719,11 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     case 2048 + 384: AP_P_LAUNCH(2048 + 384); break;
     case 1024 + 384: AP_P_LAUNCH(1024 + 384); break;
     case 0x2000: AP_P_LAUNCH(0x2000); break;
+    case 32: AP_P_LAUNCH(32); break;
+    case 64: AP_P_LAUNCH(64); break;
+    case 96: AP_P_LAUNCH(96); break;
+    case 32 + 384: AP_P_LAUNCH(32 + 384); break;
+    case 96 + 384: AP_P_LAUNCH(96 + 384); break;
     default: set_error("no such DBG instantiation"); return -22;
   }
 #else

@@ -1,5 +1,6 @@
 """Persistent vs per-tile bf16 residual block on the same inputs (tools build): the two kernels do the same arithmetic in the
-same order, so outputs must be bit-identical.  python tools/cmp_bf16_kernels.py [B] [layers ...]"""
+same order, so outputs must be bit-identical.  python tools/cmp_bf16_kernels.py [B] [layers ...]
+(AP_CMP_DBG=<bits> compares a tools variant of the persistent kernel that is meant to be exact.)"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702
 import sys, ctypes as C, torch
 from audiopure_amd import synth, _native as N
@@ -23,7 +24,7 @@ def run(layer, dbg, acc):
 bad = 0
 for layer in layers:
     for acc in (0, 1):
-        a, b = run(layer, 0, acc), run(layer, 4096, acc)
+        a, b = run(layer, int(_os.environ.get('AP_CMP_DBG', '0')), acc), run(layer, 4096, acc)
         same = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         bad += not same
         if not same:
