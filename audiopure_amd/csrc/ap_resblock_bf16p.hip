@@ -1,5 +1,6 @@
 // AP_PREC_BF16, persistent form: fused Residual_block.forward (WaveNet.py:75-97) with bf16 MFMA operands, fp32 accumulate,
-// fp32 activations in HBM -- the same arithmetic and the same packed weight images as ap_resblock_bf16.hip, restructured
+// fp32 activations in HBM -- the same arithmetic and the same packed weight images as ap_resblock_bf16.hip (outputs are
+// bit-identical: tools/cmp_bf16_kernels.py), every dilation (UA: d = 1, 2 with unaligned tap loads), restructured
 // around what the round-2 ablations measured (tools/dbg_resblock_bf16.py):
 //
 //   * with GEMM1 emptied the old kernel still took 52 % of its time, and 60 % of THAT was the residual / skip
@@ -9,11 +10,12 @@
 //
 // Here one workgroup per CU walks its tiles in a loop (XCD-local order), and the memory traffic of a tile is spread over
 // the tile and into the next one:
-//   - the h patch the residual needs is requested during GEMM1's last chunk (the staging registers are free by then), the
-//     running skip rows during the gate (the GEMM1 accumulators free up as they are gated);
-//   - the first X chunk of the NEXT tile is requested before the last epilogue's stores, so the stores of a tile drain
-//     behind the next tile's GEMM1 and no wait ever names them (vmcnt retires in order: a load issued after a store could
-//     not be waited for without waiting for the store);
+//   - the h patch the residual needs is requested before and during the gate, the running skip rows during the gate and the
+//     first epilogue (the GEMM1 accumulators free up as they are gated);
+//   - the first X chunk of the NEXT tile is requested before GEMM2's second pass and packed -- with that tile's first
+//     weight fragments and second chunk requested -- before the last epilogue's stores, so the stores of a tile drain
+//     behind the next tile's GEMM1 (vmcnt retires in order: a load issued after a store cannot be waited for without
+//     waiting for the store);
 //   - the next chunk's FiLM add / bf16 pack / ds_write sit between the MFMAs of a chunk's fourth k-step (two X buffers
 //     instead of three), so the chunk has no VALU-only tail;
 //   - no register is spilled: a scratch reload inside the tile loop is a vector-memory load whose wait (vmcnt(0)) drains
