@@ -54,6 +54,7 @@ SIGNATURES = {
     "ap_embed": (_i, [_vp, _f, _fp, _vp]),
     "ap_init_conv": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_resblock_fwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "ap_resblock_fwd_save": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_final_affine": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),
     "ap_affine_noise": (_i, [_fp, _fp, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),
     "ap_eps_fwd": (_i, [_vp, _fp, _f, _fp, _i, _i, _vp, _sz, _vp]),

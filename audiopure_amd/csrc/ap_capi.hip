@@ -358,6 +358,14 @@ extern "C" int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const 
   return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, skip, accumulate_skip, B, L, (hipStream_t)stream);
 }
 
+extern "C" int ap_resblock_fwd_save(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
+                                    float *skip, float *pre_gate, int accumulate_skip, int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !h_in || !part_t_layer || !h_out || !skip || !pre_gate) { set_error("ap_resblock_fwd_save: not loaded / null"); return -22; }
+  if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd_save: layer=%d B=%d L=%d", layer, B, L); return -22; }
+  if (h_in == h_out) { set_error("ap_resblock_fwd_save: h_out must not alias h_in"); return -22; }
+  return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, skip, accumulate_skip, B, L, (hipStream_t)stream, pre_gate);
+}
+
 extern "C" int ap_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                                float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                                int B, int L, void *stream) {

@@ -102,7 +102,7 @@ int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st);
 int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st);
 int launch_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, hipStream_t st);
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st);
+                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr);
 int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st);

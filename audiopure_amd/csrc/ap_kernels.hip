@@ -256,11 +256,14 @@ struct RBGeom {
 
 // One workgroup = one (utterance, 128-sample tile).  Per wave: 128 GEMM rows x 64 columns = 8 accumulator tiles of
 // 32x32 (128 AGPRs), so two waves share each SIMD and one wave's waits/VALU phases overlap the other's MFMAs.
-template <int C, int TTK>
+// SAVE (the differentiable path's forward pass, ap_resblock_fwd_save): the pre-gate activations y = DilConv(u) + b are also
+// written to aout [B][2C][L] (rows 0..C-1 the tanh half, C..2C-1 the sigmoid half: the layout ap_gate_bwd reads), so the
+// backward pass does not recompute the dilated conv.
+template <int C, int TTK, bool SAVE = false>
 __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1p, const float *__restrict__ b1, const float *__restrict__ w2p,
-    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles AP_ABLATE_PARAM) {
+    const float *__restrict__ b2, int L, int d, int accumulate, int ntiles, float *__restrict__ aout AP_ABLATE_PARAM) {
   AP_ABLATE_DECL
   using G = RBGeom<C, TTK>;
   constexpr int TT = TTK;   // time tile of this kernel (shadows ap::TT)
@@ -402,6 +405,14 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int c = 64 * mw + 32 * p + rowoff(r, hh);
+        if constexpr (SAVE) {
+          const int t = t0 + 32 * ct + colbase;
+          if (t < L) {
+            float *ab = aout + ((size_t)b * 2 * C + c) * L + t;
+            ab[0] = acc[2 * p][ct][r];
+            ab[(size_t)C * L] = acc[2 * p + 1][ct][r];
+          }
+        }
         lds[c * TT + 32 * ct + colbase] =
             (ablate & 2) ? acc[2 * p][ct][r] : gate(acc[2 * p][ct][r], acc[2 * p + 1][ct][r]);
       }
@@ -514,7 +525,11 @@ static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
 #endif
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st) {
+                    int accumulate, int B, int L, hipStream_t st, float *aout) {
+  if (aout && ctx->cfg.precision != AP_PREC_F32) {
+    set_error("ap_resblock_fwd_save: fp32 arithmetic only (the other modes recompute the pre-gate activations)");
+    return -22;
+  }
   if (ctx->cfg.precision != AP_PREC_F32 && !g_force_f32) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profile) {
@@ -559,8 +574,20 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   }
 #define AP_RB(CC, TK)                                                                                              \
   resblock_f32_kernel<CC, TK><<<(unsigned)B * ((L + TK - 1) / TK), CC / 64 * TK, 0, st>>>(                         \
-      hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, (L + TK - 1) / TK AP_ABLATE_ARG(g_ablate))
+      hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, (L + TK - 1) / TK, nullptr AP_ABLATE_ARG(g_ablate))
+#define AP_RB_SAVE(CC, TK)                                                                                         \
+  resblock_f32_kernel<CC, TK, true><<<(unsigned)B * ((L + TK - 1) / TK), CC / 64 * TK, 0, st>>>(                   \
+      hin, pt, hout, skip, w1p, b1, w2p, b2, L, d, accumulate, (L + TK - 1) / TK, aout AP_ABLATE_ARG(g_ablate))
   const int tk = g_tile;
+  if (aout) {
+    if (C == 256 && tk == 64) AP_RB_SAVE(256, 64);
+    else if (C == 256) AP_RB_SAVE(256, 128);
+    else if (C == 64) AP_RB_SAVE(64, 64);
+    else {
+      set_error("resblock (save): unsupported res_channels %d (need 64 or 256)", C);
+      return -22;
+    }
+  } else
   if (C == 64 && tk == 64) AP_RB(64, 64);
   else if (C == 64) AP_RB(64, 128);
   else if (C == 128 && tk == 64) AP_RB(128, 64);
@@ -572,6 +599,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
     return -22;
   }
 #undef AP_RB
+#undef AP_RB_SAVE
   if (ev1) AP_HIP(hipEventRecord(ev1, st));
   AP_HIP(hipGetLastError());
   return 0;

@@ -99,7 +99,10 @@ class EpsGrad:
             return self.net.eps(x.detach(), step)
 
     # ---- one eps evaluation, keeping what its backward needs ---------------------------------------------------
-    def forward_save(self, x: torch.Tensor, step: float):
+    def forward_save(self, x: torch.Tensor, step: float, acts: bool = True):
+        """One eps evaluation that keeps what its backward needs: every layer's input and -- ``acts`` and fp32 arithmetic --
+        every layer's pre-gate activations (``ap_resblock_fwd_save``; 3x the memory, and the backward skips the dilated
+        conv's recomputation)."""
         eng = self._prepare()
         lib, dev = eng.lib, x.device
         B, _, L = x.shape
@@ -108,20 +111,26 @@ class EpsGrad:
         N.check(lib.ap_embed(eng.ctx, float(step), N.ptr(part), N.stream()), "ap_embed")
         hs = torch.empty((NL + 1, B, C_, L), device=dev)
         skip = torch.empty((B, S_, L), device=dev)
+        pre = torch.empty((NL, B, 2 * C_, L), device=dev) if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256) else None
         N.check(lib.ap_init_conv(eng.ctx, N.ptr(x), N.ptr(hs[0]), B, L, N.stream()), "ap_init_conv")
         for n in range(NL):
-            N.check(lib.ap_resblock_fwd(eng.ctx, n, N.ptr(hs[n]), N.ptr(part[n * C_:(n + 1) * C_]), N.ptr(hs[n + 1]), N.ptr(skip),
-                                        1 if n else 0, B, L, N.stream()), "ap_resblock_fwd")
+            pt = part[n * C_:(n + 1) * C_]
+            if pre is not None:
+                N.check(lib.ap_resblock_fwd_save(eng.ctx, n, N.ptr(hs[n]), N.ptr(pt), N.ptr(hs[n + 1]), N.ptr(skip), N.ptr(pre[n]),
+                                                 1 if n else 0, B, L, N.stream()), "ap_resblock_fwd_save")
+            else:
+                N.check(lib.ap_resblock_fwd(eng.ctx, n, N.ptr(hs[n]), N.ptr(pt), N.ptr(hs[n + 1]), N.ptr(skip),
+                                            1 if n else 0, B, L, N.stream()), "ap_resblock_fwd")
         eps = torch.empty((B, 1, L), device=dev)
         N.check(lib.ap_final_affine(eng.ctx, N.ptr(skip), None, N.ptr(eps), None, 0.0, 0.0, 0.0, None, 0, 0, 0, B, L,
                                     N.stream()), "ap_final_affine")
-        return eps, (hs, skip, part)
+        return eps, (hs, skip, part, pre)
 
     def backward(self, saved, d_eps: torch.Tensor) -> torch.Tensor:
         """J_eps(x, t)^T d_eps for the evaluation ``saved`` came from."""
         eng = self._prepare()
         lib = eng.lib
-        hs, skip, part = saved
+        hs, skip, part, pre = saved
         NL, C_, S_ = self.NL, self.C, self.S
         B, L, dev = hs.shape[1], hs.shape[3], hs.device
         d_eps = d_eps.detach().float().contiguous()
@@ -138,9 +147,9 @@ class EpsGrad:
         dh = torch.zeros((B, C_, L), device=dev)                  # the last block's h' output is not used (WaveNet.py:133)
         t1 = torch.empty_like(dh)
         dg = torch.empty_like(dh)
-        u = torch.empty_like(dh)
-        a = torch.empty((B, 2 * C_, L), device=dev)
-        da = torch.empty_like(a)
+        u = torch.empty_like(dh) if pre is None else None
+        a = torch.empty((B, 2 * C_, L), device=dev) if pre is None else None
+        da = torch.empty((B, 2 * C_, L), device=dev)
         nel = dh.numel()
         for n in range(NL - 1, -1, -1):
             lay = self.layers[n]
@@ -148,11 +157,12 @@ class EpsGrad:
             N.check(lib.ap_axpbyc(N.ptr(dh), None, N.ptr(t1), _RS, 0.0, 0.0, nel, st), "ap_axpbyc")
             N.check(lib.ap_copy_channels(N.ptr(t1), N.ptr(z), B, C_, L, C_, 0, C_ + S_, 0, st), "ap_copy_channels")
             self._conv(lib, z, lay["g"], None, None, dg, B, C_ + S_, L, C_, 1, 0, 1)
-            pt = part[n * C_:(n + 1) * C_]
-            N.check(lib.ap_affine_nchw(N.ptr(hs[n]), N.ptr(self.ones), N.ptr(pt), N.ptr(u), B, C_, L, C_, 0, 0, st),
-                    "ap_affine_nchw")
-            self._conv(lib, u, lay["a"], lay["b1"], None, a, B, C_, L, 2 * C_, 3, d, d)
-            N.check(lib.ap_gate_bwd(N.ptr(a), N.ptr(dg), N.ptr(da), B, C_, L, st), "ap_gate_bwd")
+            if pre is None:                                      # not kept: recompute y = DilConv(h + part_t) + b
+                pt = part[n * C_:(n + 1) * C_]
+                N.check(lib.ap_affine_nchw(N.ptr(hs[n]), N.ptr(self.ones), N.ptr(pt), N.ptr(u), B, C_, L, C_, 0, 0, st),
+                        "ap_affine_nchw")
+                self._conv(lib, u, lay["a"], lay["b1"], None, a, B, C_, L, 2 * C_, 3, d, d)
+            N.check(lib.ap_gate_bwd(N.ptr(a if pre is None else pre[n]), N.ptr(dg), N.ptr(da), B, C_, L, st), "ap_gate_bwd")
             self._conv(lib, da, lay["u"], None, t1, dh, B, 2 * C_, L, C_, 3, d, d)
         dx = torch.empty((B, 1, L), device=dev)
         N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")
@@ -172,7 +182,7 @@ def _axpby(x, y, a, b):
     return out
 
 
-SAVE_BUDGET_BYTES = 48 << 30      # per chain: keep the links' layer inputs when they fit (288 GB of HBM), else recompute
+SAVE_BUDGET_BYTES = 96 << 30      # per chain: what the links keep for the backward pass while it fits (288 GB of HBM)
 
 
 def _saved_bytes(saved) -> int:
@@ -192,10 +202,11 @@ def _saved_bytes(saved) -> int:
 class _ChainFn(torch.autograd.Function):
     """x_out = chain(x_in): q-sample then the links (step, ca, cb, cs); noise tensors given explicitly.
 
-    Every elementwise update is an ``ap_axpbyc`` call.  A link's eps-evaluation keeps its per-layer inputs for the backward
-    pass while the chain's total stays under ``SAVE_BUDGET_BYTES`` (one evaluation of the shipped net is 0.6 GB per clip:
-    a PGD batch of 8 clips x 5 links is 24 GB of the 288); beyond the budget only the state entering the link is kept and
-    the evaluation is recomputed in the backward pass (the adjoint's trade: compute for memory)."""
+    Every elementwise update is an ``ap_axpbyc`` call.  A link's eps-evaluation keeps its per-layer inputs and (fp32
+    arithmetic) pre-gate activations for the backward pass while the chain's total stays under ``SAVE_BUDGET_BYTES`` (one
+    evaluation of the shipped net is 1.8 GB per clip that way, 0.6 GB with the layer inputs only: a PGD batch of 8 clips x
+    5 links is 72 GB of the 288); past the budget a link keeps the layer inputs only (its backward recomputes the dilated
+    conv), then only the state entering it (the evaluation is recomputed in the backward pass: the adjoint's trade)."""
 
     @staticmethod
     def forward(ctx, x, grad, steps, qa, qs, zs):
@@ -208,18 +219,22 @@ class _ChainFn(torch.autograd.Function):
                 cur = _axpby(cur, zs[0], qa, qs)
             elif qa != 1.0:
                 cur = _axpby(cur, None, qa, 0.0)
-            per_link = None
+            full = lean = None                                   # bytes a link keeps with / without the pre-gate activations
             for (t, ca, cb, cs, draw) in steps:
                 xs.append(cur)
-                keep = per_link is None or held + per_link <= SAVE_BUDGET_BYTES
-                if keep:
+                if full is None or held + full <= SAVE_BUDGET_BYTES:
                     eps, saved = grad.forward_save(cur, t)
-                    if per_link is None:
-                        per_link = _saved_bytes(saved)
-                        if per_link > SAVE_BUDGET_BYTES:
-                            saved = None
+                    if full is None:
+                        full = _saved_bytes(saved)
+                        lean = _saved_bytes(saved[:3]) if isinstance(saved, tuple) and len(saved) == 4 else full
+                        if full > SAVE_BUDGET_BYTES:
+                            saved = None if lean > SAVE_BUDGET_BYTES else saved[:3] + (None,)
                     if saved is not None:
-                        held += per_link
+                        held += _saved_bytes(saved)
+                    saves.append(saved)
+                elif lean < full and held + lean <= SAVE_BUDGET_BYTES:
+                    eps, saved = grad.forward_save(cur, t, acts=False)    # layer inputs only: the backward recomputes the dilated conv
+                    held += lean
                     saves.append(saved)
                 else:
                     eps = eps_only(cur, t) if eps_only is not None else grad.forward_save(cur, t)[0]

@@ -144,6 +144,13 @@ int ap_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, void *stre
 int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer,
                     float *h_out, float *skip, int accumulate_skip, int B, int L, void *stream);
 
+/* ap_resblock_fwd_save: ap_resblock_fwd that also writes the pre-gate activations y = DilConv(u) + b (WaveNet.py:87) to
+ * pre_gate [B][2C][L] (rows 0..C-1 the tanh half, C..2C-1 the sigmoid half): what the backward of :90 needs, kept by the
+ * differentiable purifier (the reference's autograd keeps it too) so that the adjoint does not recompute the dilated conv.
+ * AP_PREC_F32 contexts only (-22 otherwise). */
+int ap_resblock_fwd_save(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out, float *skip,
+                         float *pre_gate, int accumulate_skip, int B, int L, void *stream);
+
 /* ap_final_affine: final_conv (WaveNet.py:160-162,170) on skip*sqrt(1/N) (WaveNet.py:135) fused
  * with an affine update of the clip:  eps = W_f2 ReLU(W_f1 (skip*sqrt(1/N)) + b_f1) + b_f2;
  *   out = ca * x + cb * eps + cs * z.

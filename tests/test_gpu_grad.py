@@ -55,6 +55,41 @@ def test_eps_vjp_matches_oracle_autograd(dev, C_, NL, L, step):
     assert rel_err(g.cpu().numpy(), g_ref.numpy()) < 1e-4
 
 
+def test_eps_vjp_is_the_same_with_kept_and_with_recomputed_pre_gate_activations(dev):
+    """ap_resblock_fwd_save keeps y = DilConv(u) + b per layer; without it the backward recomputes y with ap_conv2d_fwd.
+    Same gradient either way (the fused block and the conv kernel sum K = 3C in different orders: 1e-5), and the chain
+    falls back level by level when SAVE_BUDGET_BYTES is short (full -> layer inputs only -> recompute the link)."""
+    from audiopure_amd.diffusion_models import _grad as G
+    cfg = synth.mini_wavenet_config(256, 3, 12)
+    net, _ = _net(cfg, dev, seed=7)
+    B, L, step = 2, 1100, 4.0
+    x = torch.from_numpy(synth.waveforms(B, L, seed=13)).to(dev)
+    v = torch.from_numpy(synth.uniform("vk", (B, 1, L), 1, -1.0, 1.0)).to(dev)
+    eg = G.EpsGrad(net)
+    eps_a, saved_a = eg.forward_save(x, step)
+    eps_b, saved_b = eg.forward_save(x, step, acts=False)
+    assert saved_a[3] is not None and saved_a[3].shape == (3, B, 512, L) and saved_b[3] is None
+    assert torch.equal(eps_a, eps_b)
+    ga, gb = eg.backward(saved_a, v), eg.backward(saved_b, v)
+    assert rel_err(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-5
+    # chain level: three links under a budget that holds (a) everything, (b) one full link + lean ones, (c) nothing
+    steps = [(2.0, 1.01, -0.02, 0.01, 1), (1.0, 1.01, -0.02, 0.01, 2), (0.0, 1.0, -0.01, 0.0, 0)]
+    zs = [torch.from_numpy(synth.noise(dr, B, L, seed=14)).to(dev) for dr in range(3)]
+    full = G._saved_bytes(saved_a)
+    grads = []
+    old = G.SAVE_BUDGET_BYTES
+    try:
+        for budget in (old, full + 2 * G._saved_bytes(saved_a[:3]) + 1, 1):
+            G.SAVE_BUDGET_BYTES = budget
+            xg = x.clone().requires_grad_(True)
+            out = G.differentiable_chain(net, xg, steps, 0.9, 0.1, zs)
+            (out * v).sum().backward()
+            grads.append(xg.grad.cpu().numpy())
+    finally:
+        G.SAVE_BUDGET_BYTES = old
+    assert rel_err(grads[1], grads[0]) < 1e-5 and rel_err(grads[2], grads[0]) < 1e-5
+
+
 @pytest.mark.parametrize("mode", ["f32s", "f32h"])
 def test_eps_vjp_in_the_split_modes_matches_oracle_autograd(dev, mode):
     """The same check with the network in a split-operand mode (fused block forward in that mode, the backward GEMMs on
