@@ -504,14 +504,16 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
         if (rt < 2) {
 #pragma unroll
           for (int r = 0; r < 16; r++)
-            ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = (hres[rt][ct][r] + acc[rt][ct][r]) * RS;
+            // nt (also the skip store below): once-written streams must not displace the h rows in the XCD's L2, which
+            // neighbouring tiles' taps and the residual read again
+            __builtin_nontemporal_store((hres[rt][ct][r] + acc[rt][ct][r]) * RS, &ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L]);
         } else if (accumulate) {
 #pragma unroll
           for (int r = 0; r < 16; r++)
             unsafeAtomicAdd(&sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L], acc[rt][ct][r]);
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; r++) sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L] = acc[rt][ct][r];
+          for (int r = 0; r < 16; r++) __builtin_nontemporal_store(acc[rt][ct][r], &sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L]);
         }
       }
     }

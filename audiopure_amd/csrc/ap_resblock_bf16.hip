@@ -561,7 +561,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 #pragma unroll
           for (int p = 0; p < 4; p++) {
             const f32x4 v = __builtin_bit_cast(
-                f32x4, __builtin_amdgcn_raw_buffer_load_b128(pass == 0 ? hrs : srs, evoff[ct], 8 * p * L * 4, 0));
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(pass == 0 ? hrs : srs, evoff[ct], 8 * p * L * 4, pass == 0 ? 0 : 2));
 #pragma unroll
             for (int i = 0; i < 4; i++) pre[ct][4 * p + i] = v[i];
           }
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
 #pragma unroll
           for (int r = 0; r < 16; r++)
             pre[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                       pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+                                                       pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, pass == 0 ? 0 : 2));
         }
       }
     }
@@ -641,14 +641,14 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
             // late, and the compiler here does not guard the next write of those VGPRs (observed: torn y lanes)
             if constexpr (DBG & 256) asm volatile("" :: "v"(o));                                     // timing-only: no stores
             else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), pass == 0 ? ors : srs,
-                                                        evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0);
+                                                        evoff[ct] + (unsigned)(8 * p * L * 4), 0, 2);
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; r++)
             __builtin_amdgcn_raw_buffer_store_b32(
                 __builtin_bit_cast(unsigned, ((add ? pre[ct][r] : 0.f) + ac[ct][r]) * scale), pass == 0 ? ors : srs,
-                evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
+                evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 2);
         }
       }
     }

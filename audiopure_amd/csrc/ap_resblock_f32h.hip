@@ -433,7 +433,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
 #pragma unroll
         for (int p = 0; p < 4; p++) {
           const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        pass == 0 ? hrs : srs, evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0));
+                                                        pass == 0 ? hrs : srs, evoff[ct] + (unsigned)(8 * p * L * 4), 0, pass == 0 ? 0 : 2));
 #pragma unroll
           for (int i = 0; i < 4; i++) pre[ct][4 * p + i] = v[i];
         }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++)
           pre[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                     pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+                                                     pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, pass == 0 ? 0 : 2));
       }
     }
     f32x16 ac[4];
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
             o[3] = __builtin_fmaf(pre[ct][4 * p + 3], addm, v.w) * scale;
             // offset in the VGPR, soffset = 0 (a >8-byte buffer store with an SGPR soffset reads its data late)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), pass == 0 ? ors : srs,
-                                                   evoff[ct] + (unsigned)(8 * p * L * 4), 0, 0);
+                                                   evoff[ct] + (unsigned)(8 * p * L * 4), 0, 2);
           }
         }
       } else {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
         for (int r = 0; r < 16; r++)
           __builtin_amdgcn_raw_buffer_store_b32(
               __builtin_bit_cast(unsigned, __builtin_fmaf(pre[ct][r], addm, ac[ct][r]) * scale), pass == 0 ? ors : srs,
-              evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
+              evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 2);
       }
     }
   };

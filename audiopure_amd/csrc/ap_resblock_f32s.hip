@@ -403,7 +403,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
 #pragma unroll
           for (int p = 0; p < 4; p++) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          pass == 0 ? hrs : srs, evoff[c2] + (unsigned)(8 * p * L * 4), 0, 0));
+                                                          pass == 0 ? hrs : srs, evoff[c2] + (unsigned)(8 * p * L * 4), 0, pass == 0 ? 0 : 2));
 #pragma unroll
             for (int i = 0; i < 4; i++) pre[c2][4 * p + i] = v[i];
           }
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
 #pragma unroll
           for (int r = 0; r < 16; r++)
             pre[c2][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                       pass == 0 ? hrs : srs, evoff[c2], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+                                                       pass == 0 ? hrs : srs, evoff[c2], ((r & 3) + 8 * (r >> 2)) * L * 4, pass == 0 ? 0 : 2));
         }
       }
       f32x16 ac[2];
@@ -483,14 +483,14 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
             o[3] = __builtin_fmaf(pre[c2][4 * p + 3], addm, v.w) * scale;
             // offset in the VGPR, soffset = 0 (a >8-byte buffer store with an SGPR soffset reads its data late)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), pass == 0 ? ors : srs,
-                                                   evoff[c2] + (unsigned)(8 * p * L * 4), 0, 0);
+                                                   evoff[c2] + (unsigned)(8 * p * L * 4), 0, 2);
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; r++)
             __builtin_amdgcn_raw_buffer_store_b32(
                 __builtin_bit_cast(unsigned, __builtin_fmaf(pre[c2][r], addm, ac[c2][r]) * scale), pass == 0 ? ors : srs,
-                evoff[c2], ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
+                evoff[c2], ((r & 3) + 8 * (r >> 2)) * L * 4, 2);
         }
       }
     };
