@@ -147,9 +147,22 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   }
 
   float xr[32];
+  // walk order inside a clip: for d >= 2 tiles the +-d taps of a tile are the centre columns of tiles s = d / PT_ away, and the
+  // 32 tiles an XCD holds at a time are 32 consecutive walk positions.  Position p -> tile r + k s (residue classes r = 0..s-1
+  // in turn, s capped at 16), so that a window of 32 positions holds whole runs ..., j - s, j, j + s, ...: L2-miss reads of
+  // the d = 1024 / 2048 layers 28.5 / 31.9 -> see profiles/r2_bf16_fetch_by_layer.txt.  Placement only: results unchanged.
+  const int wstep = __builtin_amdgcn_readfirstlane(min(max(d / PT_, 1), 16));
+  const int wq = ntiles / wstep, wrem = ntiles % wstep;
   auto tile_bt = [&](int tile, int &b, int &t0) {
     b = __builtin_amdgcn_readfirstlane(tile / ntiles);
-    t0 = __builtin_amdgcn_readfirstlane((tile % ntiles) * PT_);
+    int p = tile % ntiles;
+    if ((DBG & 0x8000) == 0 && wstep > 1) {
+      const int cut = wrem * (wq + 1);
+      const int r = p < cut ? p / (wq + 1) : wrem + (p - cut) / wq;
+      const int k = p < cut ? p % (wq + 1) : (p - cut) % wq;
+      p = r + k * wstep;
+    }
+    t0 = __builtin_amdgcn_readfirstlane(p * PT_);
   };
   // zero padding (WaveNet.py:26-27) as an AND mask on the packed values.  d % 4 == 0: a column quad is inside the clip or
   // outside it as a whole, the address is clamped.  UA (d = 1, 2): unaligned 16-byte loads, one mask per sample; a sample
@@ -726,6 +739,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     case 1024 + 384: AP_P_LAUNCH(1024 + 384); break;
     case 0x2000: AP_P_LAUNCH(0x2000); break;
     case 0x4000: AP_P_LAUNCH(0x4000); break;
+    case 0x8000: AP_P_LAUNCH(0x8000); break;
     case 32: AP_P_LAUNCH(32); break;
     case 64: AP_P_LAUNCH(64); break;
     case 96: AP_P_LAUNCH(96); break;

@@ -46,3 +46,4 @@ timeout 200 python3 "$repo/tools/trace_resblock_bf16p.py" 256 9 > "$repo/$out/ph
 timeout 400 python3 "$repo/tools/dbg_resblock_bf16.py" 256 0 4096 1 2 3 4 8 128 256 384 512 1024 8192 > "$repo/$out/ablation.txt" 2>&1
 timeout 200 python3 "$repo/tools/cmp_bf16_kernels.py" 4 > "$repo/$out/cmp_kernels.txt" 2>&1
 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 "$repo/bench.py" --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-other-configs > "$repo/$out/bench_torchrun_n1.json" 2> "$repo/$out/bench_torchrun_n1.err"
+bash "$repo/tools/fetch_by_layer.sh" > "$repo/$out/fetch_by_layer.txt" 2>&1
