@@ -97,6 +97,30 @@ struct ap_m5 {
 };
 
 // kernel launchers (defined in the .hip files)
+#ifdef __HIPCC__
+namespace ap {
+// Which (clip, tile) a workgroup of a one-tile-per-workgroup block kernel takes.  Placement only -- any bijection gives the same
+// results; this one is for the per-XCD L2s: workgroups b, b + 8, ... share an XCD (round-robin dispatch), so each XCD takes a
+// contiguous run of (clip, position) work, and inside a clip position p maps to tile r + k s (residue classes r = 0 .. s-1 in
+// turn, s = dilation / tile width capped at 16): the tiles an XCD holds at one time then include the ones d columns away,
+// whose centre columns are this tile's +-d taps.
+__device__ __forceinline__ void ap_tile_of_block(int bid, int nblk, int ntiles, int d, int tile_cols, int &b, int &tile) {
+  const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+  const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  b = logical / ntiles;
+  int p = logical % ntiles;
+  const int s = min(max(d / tile_cols, 1), 16);
+  if (s > 1) {
+    const int wq = ntiles / s, wrem = ntiles % s, cut = wrem * (wq + 1);
+    const int cls = p < cut ? p / (wq + 1) : wrem + (p - cut) / wq;
+    const int k = p < cut ? p % (wq + 1) : (p - cut) % wq;
+    p = cls + k * s;
+  }
+  tile = p;
+}
+}  // namespace ap
+#endif
+
 namespace ap {
 int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st);
 int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st);

@@ -275,8 +275,10 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mw = wave / G::NWN, nw = wave % G::NWN;
   const int j = lane & 31, hh = lane >> 5;
-  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x / ntiles);
-  const int t0 = __builtin_amdgcn_readfirstlane((blockIdx.x % ntiles) * TT);
+  int b_, tile_;
+  ap_tile_of_block(blockIdx.x, gridDim.x, ntiles, d, TT, b_, tile_);      // XCD-local walk (speed only)
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int t0 = __builtin_amdgcn_readfirstlane(tile_ * TT);
   const float *hin_b;
   {   // make the per-utterance base provably wave-uniform (buffer descriptor must live in SGPRs)
     const uint64_t hb = (uint64_t)(hin + (size_t)b * C * L);

@@ -145,13 +145,10 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_bf16_kernel(
   mark(0);
   // XCD-local order: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a contiguous run of
   // (clip, tile) work so the +-d taps and the residual patch of a clip are re-read from that XCD's L2.
-  int logical;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int b = __builtin_amdgcn_readfirstlane(logical / ntiles);
-  const int t0 = __builtin_amdgcn_readfirstlane((logical % ntiles) * BT);
+  int b_, tile_;                                               // XCD-local walk (ap_common.h; speed only)
+  ap_tile_of_block(blockIdx.x, nblk, ntiles, d, BT, b_, tile_);
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int t0 = __builtin_amdgcn_readfirstlane(tile_ * BT);
   const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
   auto clip_rsrc = [&](const float *base) {
     const uint64_t hb = (uint64_t)(base + (size_t)b * C * L);

@@ -169,13 +169,10 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
     }
   };
   mark(0);
-  int logical;                                                 // XCD-local tile order (see ap_resblock_bf16.hip)
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int b = __builtin_amdgcn_readfirstlane(logical / ntiles);
-  const int t0 = __builtin_amdgcn_readfirstlane((logical % ntiles) * BT);
+  int b_, tile_;                                               // XCD-local walk (ap_common.h; speed only)
+  ap_tile_of_block(blockIdx.x, nblk, ntiles, d, BT, b_, tile_);
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int t0 = __builtin_amdgcn_readfirstlane(tile_ * BT);
   const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
   auto clip_rsrc = [&](const float *base) {
     const uint64_t hb = (uint64_t)(base + (size_t)b * C * L);
