@@ -472,7 +472,7 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++)
           hres[rt][ct][r] = __builtin_bit_cast(
-              float, __builtin_amdgcn_raw_buffer_load_b32(hrs, evoff[rt][ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 0));
+              float, __builtin_amdgcn_raw_buffer_load_b32(hrs, evoff[rt][ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 2));   // nt: hits or passes without allocating
   }
 
   {

@@ -85,9 +85,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const void *__restrict__ bbase, unsigned bbytes, unsigned b1_off, unsigned b2_off,        // fp32 bias vectors (one slab)
     int L, int d, int accumulate, int ntiles, int nblk) {
   constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
-  // cache policy of the once-touched streams (the running skip rows in, both outputs out): nt (aux bit 1) keeps them from
-  // displacing the h rows in the XCD's L2, which are read by three taps of neighbouring tiles and once more for the residual:
-  // L2-miss reads 27.2 -> 22.6 GB per 512-clip launch (traffic 1.31 -> 1.17 x algorithmic).  DBG 0x4000: default policy.
+  // cache policy: nt (aux bit 1) on the once-touched streams (the running skip rows in, both outputs out) and on the residual's
+  // re-read of h (it hits what is still there and allocates nothing on a miss).  Only the tap loads and the weights allocate in
+  // the XCD's L2, so h rows stay until the neighbouring tiles' taps and the residual have read them again: L2-miss reads 27.2 ->
+  // 19.4 GB per 512-clip launch (traffic 1.31 -> 1.08 x algorithmic), -3 % time.  DBG 0x4000: default policy everywhere.
   constexpr int NT = (DBG & 0x4000) ? 0 : 2;
   constexpr int XBYTES = PT_ * XS_ * 2;                         // 26,624 B per X buffer, two buffers
   constexpr int GOFF = 2 * XBYTES;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       } else {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, evoff[ct], 8 * p * L * 4, 0));
+          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, evoff[ct], 8 * p * L * 4, NT));
 #pragma unroll
           for (int i = 0; i < 4; i++) pre[ct][4 * p + i] = v[i];
         }

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
 #pragma unroll
         for (int p = 0; p < 4; p++) {
           const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                        pass == 0 ? hrs : srs, evoff[ct] + (unsigned)(8 * p * L * 4), 0, pass == 0 ? 0 : 2));
+                                                        pass == 0 ? hrs : srs, evoff[ct] + (unsigned)(8 * p * L * 4), 0, 2));   // nt: once-touched skip rows; the residual re-read of h hits or passes without allocating
 #pragma unroll
           for (int i = 0; i < 4; i++) pre[ct][4 * p + i] = v[i];
         }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32h_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++)
           pre[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                     pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, pass == 0 ? 0 : 2));
+                                                     pass == 0 ? hrs : srs, evoff[ct], ((r & 3) + 8 * (r >> 2)) * L * 4, 2));   // nt: once-touched skip rows; the residual re-read of h hits or passes without allocating
       }
     }
     f32x16 ac[4];

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
 #pragma unroll
           for (int p = 0; p < 4; p++) {
             const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          pass == 0 ? hrs : srs, evoff[c2] + (unsigned)(8 * p * L * 4), 0, pass == 0 ? 0 : 2));
+                                                          pass == 0 ? hrs : srs, evoff[c2] + (unsigned)(8 * p * L * 4), 0, 2));   // nt: once-touched skip rows; the residual re-read of h hits or passes without allocating
 #pragma unroll
             for (int i = 0; i < 4; i++) pre[c2][4 * p + i] = v[i];
           }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(C / 32 * 64, 2) void resblock_f32s_kernel(
 #pragma unroll
           for (int r = 0; r < 16; r++)
             pre[c2][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                       pass == 0 ? hrs : srs, evoff[c2], ((r & 3) + 8 * (r >> 2)) * L * 4, pass == 0 ? 0 : 2));
+                                                       pass == 0 ? hrs : srs, evoff[c2], ((r & 3) + 8 * (r >> 2)) * L * 4, 2));   // nt: once-touched skip rows; the residual re-read of h hits or passes without allocating
         }
       }
       f32x16 ac[2];
