@@ -77,7 +77,8 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 
 // DBG (tools builds only; outputs wrong by construction): 1 no weight loads in GEMM1's loop, 2 no X loads, 4 no pack,
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
-// 256 no stores, 512 no per-chunk barrier, 1024 every tile stages the same 128 columns of clip 0, 2048 phase stamps, 0x2000 no priority swap.
+// 256 no stores, 512 no per-chunk barrier, 1024 every tile stages the same 128 columns of clip 0, 2048 phase stamps, 0x2000 no priority swap,
+// 0x4000 default cache policy instead of nt (exact), 0x8000 contiguous walk inside a clip for every dilation (exact).
 template <int DBG, bool UA = false>
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
