@@ -228,7 +228,7 @@ int ap_m5_fwd(ap_m5 *m, const float *x, float *logprobs, int B, int L, void *str
  * transforms/transforms_stft.py:101-114 (ToSTFT + ToMelSpectrogramFromSTFT). */
 int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L, void *stream);
 
-/* ---- 2-D ConvNet classifiers on the mel front-end (audio_models/ConvNets_SpeechCommands/models/*: vgg.py, resnet.py,
+/* ---- 2-D ConvNet classifiers on the mel front-end (audio_models/ConvNets_SpeechCommands/models/ : vgg.py, resnet.py,
  * wideresnet.py, resnext.py:67-142, dpn.py, densenet.py).  The host lowers an eval-mode network
  * to these NCHW fp32 primitives (audiopure_amd/convnet.py); BatchNorm is folded into the conv or applied as a
  * per-channel affine.  `*_cstride` / `*_coff`: the operand is channels [coff, coff+C) of a tensor with cstride channels
