@@ -1,6 +1,6 @@
 // AP_PREC_BF16, persistent form: fused Residual_block.forward (WaveNet.py:75-97) with bf16 MFMA operands, fp32 accumulate,
 // fp32 activations in HBM -- the same arithmetic and the same packed weight images as ap_resblock_bf16.hip (outputs are
-// bit-identical: tools/cmp_bf16_kernels.py), every dilation (UA: d = 1, 2 with unaligned tap loads), restructured
+// bit-identical: tools/cmp_bf16_kernels.py), every dilation (d <= 32 stages one 192-column window per chunk for the three taps), restructured
 // around what the round-2 ablations measured (tools/dbg_resblock_bf16.py):
 //
 //   * with GEMM1 emptied the old kernel still took 52 % of its time, and 60 % of THAT was the residual / skip
@@ -79,7 +79,7 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
 // 256 no stores, 512 no per-chunk barrier, 1024 every tile stages the same 128 columns of clip 0, 2048 phase stamps, 0x2000 no priority swap,
 // 0x4000 default cache policy instead of nt (exact), 0x8000 contiguous walk inside a clip for every dilation (exact).
-template <int DBG, bool UA = false>
+template <int DBG, int WS = -1>              // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // the XCD's L2, so h rows stay until the neighbouring tiles' taps and the residual have read them again: L2-miss reads 27.2 ->
   // 19.4 GB per 512-clip launch (traffic 1.31 -> 1.08 x algorithmic), -3 % time.  DBG 0x4000: default policy everywhere.
   constexpr int NT = (DBG & 0x4000) ? 0 : 2;
-  constexpr int XBYTES = PT_ * XS_ * 2;                         // 26,624 B per X buffer, two buffers
+  constexpr bool WIN = WS >= 0;
+  constexpr int XBYTES = (PT_ + (WIN ? 4 : 0)) * XS_ * 2;       // 26,624 B per X buffer (WIN: + a scratch column quad), two buffers
   constexpr int GOFF = 2 * XBYTES;
   constexpr int POFF = GOFF + PT_ * GS_ * 2;                   // output patches: 8 waves x 32 x 32 fp32
   constexpr int PTOFF = POFF + NW * 32 * PS_ * 4;              // part_t (C floats)
@@ -166,30 +167,44 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     }
     t0 = __builtin_amdgcn_readfirstlane(p * PT_);
   };
-  // zero padding (WaveNet.py:26-27) as an AND mask on the packed values.  d % 4 == 0: a column quad is inside the clip or
-  // outside it as a whole, the address is clamped.  UA (d = 1, 2): unaligned 16-byte loads, one mask per sample; a sample
-  // after a row's end reads the next row (beyond the clip: the descriptor returns 0) and is masked.  Before the clip's
-  // first sample there is no address to give (buffer offsets are unsigned, and a 16-byte load that starts out of range
-  // returns zeros for all four dwords): those lanes -- column quad 0 of the -d tap in a clip's first tile -- load samples
-  // 0..3 and move them up by d registers before the pack (fix_x; wave-uniform test, one tile in ntiles).
-  struct Keep { unsigned m[UA ? 4 : 1]; bool fix, neg; };
+  // zero padding (WaveNet.py:26-27) as an AND mask on the packed values: a column quad is inside the clip or outside it as a
+  // whole (L % 4 == 0), the address is clamped.
+  // WIN (d <= 32): the three taps of a tile are the same 128 + 2d columns, so a chunk stages ONE window of 192 columns
+  // [t0 - 32, t0 + 160) -- 24.6 KB of loads instead of 64 KB -- converts every value once and writes it to the up to three
+  // (column, tap) places of the X image it belongs to (ds_write_b64: four channels of one column).  A staging unit is
+  // (column quad sq of 48, channel quad wc4 of 8): waves 0-5, lane bits (low to high) wc4, sq & 7, so a load covers eight
+  // channel rows x 128 B and the sixteen lanes of a ds_write_b64 group cover all 32 banks.  The four samples of a unit land,
+  // per tap, in one image quad (d % 4 == 0) or in two neighbouring ones (d = 1, 2): one address register per (tap, quad),
+  // the sample's place inside the quad is an immediate.  A quad outside columns 0..127 is the scratch quad 128..131.
+  struct Keep { unsigned m[1]; };
   Keep keep;
+  const int sq = min(wave, 5) * 8 + (lane >> 3), wc4 = lane & 7;
+  unsigned xwb[WIN ? 3 : 1][WIN ? 2 : 1];                      // [tap][first / second image quad of the unit's samples]
+  if constexpr (WIN) {
+#pragma unroll
+    for (int T = 0; T < 3; T++) {
+      const int qa = sq - 8 + ((T == 2 && WS != 0) ? -1 : 0) - (WS == 0 ? (T - 1) * (d >> 2) : 0);   // image quad of sample 0
+#pragma unroll
+      for (int h2 = 0; h2 < 2; h2++) {
+        const int q = qa + h2;
+        const int qc = (q >= 0 && q < PT_ / 4) ? q : PT_ / 4;
+        xwb[T][h2] = (unsigned)(4 * qc * (XS_ * 2) + ((T * 2 * KC_ + wc4 * 8) ^ ((__builtin_popcount(qc & 7) & 1) << 5)));
+      }
+    }
+  }
   auto x_geom = [&](int t0_in, unsigned &voff, Keep &k) {
     const int t0 = (DBG & 1024) ? 8192 : t0_in;                  // timing-only: every tile stages the same 128 columns of clip 0
-    // the lane's column quad and channel octet are re-derived from a lane id read here (volatile asm: not hoisted out of the
-    // tile loop): kept from the prologue they were spilled, and a scratch reload waits with vmcnt(0) -- here, behind the
-    // first epilogue's stores
+    // the lane's geometry is re-derived from a lane id read here (volatile asm: not hoisted out of the tile loop): kept from
+    // the prologue it was spilled, and a scratch reload waits with vmcnt(0) -- here, behind the first epilogue's stores
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    const int cg = ((wave & 1) * 4 + (ln >> 4)) * 4 + (ln & 3), oct = (ln >> 2) & 3;
-    const int tp = t0 + 4 * cg + (xtap - 1) * d;
-    if constexpr (UA) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) k.m[i] = (tp + i >= 0 && tp + i < L) ? 0xffffffffu : 0u;
-      k.neg = tp < 0;
-      k.fix = (t0 == 0) && (xtap == 0);
-      voff = (unsigned)(max(tp, 0) + oct * 8 * L) * 4u;
+    if constexpr (WIN) {
+      const int tq = t0 - 32 + 4 * (min(wave, 5) * 8 + (ln >> 3));
+      k.m[0] = (tq >= 0 && tq < L) ? 0xffffffffu : 0u;
+      voff = ((unsigned)min(max(tq, 0), L - 4) + (unsigned)((ln & 7) * 4) * (unsigned)L) * 4u;
     } else {
+      const int cg = ((wave & 1) * 4 + (ln >> 4)) * 4 + (ln & 3), oct = (ln >> 2) & 3;
+      const int tp = t0 + 4 * cg + (xtap - 1) * d;
       k.m[0] = (tp >= 0 && tp < L) ? 0xffffffffu : 0u;
       voff = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
     }
@@ -204,45 +219,64 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     for (int i = 0; i < 4; i++) xr[e * 4 + i] = v[i];
   };
   auto issue_x = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch) {
+    if constexpr (WIN) {
+      if (wave < 6) {                                            // wave-uniform
 #pragma unroll
-    for (int e = 0; e < 8; e++) issue_x1(rs_in, voff, ch, e);
+        for (int e = 0; e < 4; e++) issue_x1(rs_in, voff, ch, e);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) issue_x1(rs_in, voff, ch, e);
+    }
   };
   float ptv8[8];
   u32x4 pkq;
-  auto fix_x = [&]() {
-    if constexpr (UA) {
-      if (keep.fix) {                                           // wave-uniform
-#pragma unroll
-        for (int e = 0; e < 8; e++)
-#pragma unroll
-          for (int i = 3; i >= 1; i--) {
-            const float lo = xr[e * 4 + (i >= 2 ? i - 2 : 0)], mid = xr[e * 4 + i - 1];
-            xr[e * 4 + i] = keep.neg ? (d == 2 ? lo : mid) : xr[e * 4 + i];
-          }
-      }
-    }
-  };
   auto pack_ptv = [&](int ch) {
-    fix_x();
     int ln;                                                     // (lane id read here, not kept: see x_geom)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-    const float *ptc = reinterpret_cast<const float *>(lds + PTOFF) + ((ln >> 2) & 3) * 8 + ch * KC_;
-    const float4 p0 = *reinterpret_cast<const float4 *>(ptc);
-    const float4 p1 = *reinterpret_cast<const float4 *>(ptc + 4);
-    ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
-    ptv8[4] = p1.x; ptv8[5] = p1.y; ptv8[6] = p1.z; ptv8[7] = p1.w;
+    if constexpr (WIN) {
+      const float4 p0 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lds + PTOFF) + (ln & 7) * 4 + ch * KC_);
+      ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
+    } else {
+      const float *ptc = reinterpret_cast<const float *>(lds + PTOFF) + ((ln >> 2) & 3) * 8 + ch * KC_;
+      const float4 p0 = *reinterpret_cast<const float4 *>(ptc);
+      const float4 p1 = *reinterpret_cast<const float4 *>(ptc + 4);
+      ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
+      ptv8[4] = p1.x; ptv8[5] = p1.y; ptv8[6] = p1.z; ptv8[7] = p1.w;
+    }
   };
-  // one eighth of a chunk's staging: sample i, channel pairs 2hf, 2hf+1 -> 4 adds, 2 cvt_pk, 2 and; the ds_write_b128 follows
-  // a sample's second piece.  FiLM add (WaveNet.py:84), zero padding (:26-27) as an AND with the in-range mask.
+  // one eighth of a chunk's staging.  FiLM add (WaveNet.py:84), zero padding (:26-27) as an AND with the in-range mask.
+  //   !WIN: sample i, channel pairs 2hf, 2hf+1 -> 4 adds, 2 cvt_pk, 2 and; the ds_write_b128 follows a sample's second piece.
+  //   WIN:  sample i: piece 0 = 4 adds, 2 cvt_pk, 2 and (four channels); piece 1 = its three ds_write_b64 (taps -d, 0, +d).
   auto pack_piece = [&](unsigned char *dst, const Keep &keep, auto i_tag, auto hf_tag) {
     constexpr int i = decltype(i_tag)::value, hf = decltype(hf_tag)::value;
     if constexpr (DBG & 4) return;
+    if constexpr (WIN) {
+      if (wave < 6) {                                            // wave-uniform
+        if constexpr (hf == 0) {
 #pragma unroll
-    for (int e2 = 2 * hf; e2 < 2 * hf + 2; e2++)
-      pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
-                                                 f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
-                                                       xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep.m[UA ? i : 0];
-    if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS_ + xk) * 2) = pkq;
+          for (int e2 = 0; e2 < 2; e2++)
+            pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                                                       f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
+                                                             xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep.m[0];
+        } else {
+#pragma unroll
+          for (int T = 0; T < 3; T++) {
+            // place of sample 0 inside its image quad: tap -d: d mod 4; centre: 0; tap +d: (-d) mod 4
+            const int a0 = WS == 0 || T == 1 ? 0 : (T == 0 ? WS : 4 - WS);
+            const int pos = a0 + i;
+            *reinterpret_cast<uint2 *>(dst + xwb[T][pos >> 2] + (pos & 3) * (XS_ * 2)) = make_uint2(pkq[0], pkq[1]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e2 = 2 * hf; e2 < 2 * hf + 2; e2++)
+        pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
+                                                   f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
+                                                         xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep.m[0];
+      if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS_ + xk) * 2) = pkq;
+    }
   };
   auto pack_all = [&](unsigned char *dst, const Keep &keep, int ch) {
     pack_ptv(ch);
@@ -522,6 +556,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     };
     auto gate_ct = [&](auto ct_tag) {
       constexpr int ct = decltype(ct_tag)::value;
+      int ln;                                                    // (lane id read here, not kept: see x_geom)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int j = ln & 31, hh = ln >> 5;
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
         unsigned pk[2];
@@ -677,7 +714,9 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   if (C != 256 || S != 256 || (L % 4) != 0 || L < 4) return 1;
-  const bool ua = (d % 4) != 0;
+  // staging form: one window for the three taps where they overlap (d <= 32), else three tap loads
+  const int ws = d == 1 ? 1 : d == 2 ? 2 : (d <= 32 && d % 4 == 0) ? 0 : d < 4 ? -2 : -1;
+  if (ws == -2) return 1;                                        // (d = 3: no such dilation in a power-of-two cycle)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, n = 0;
@@ -703,10 +742,16 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 #define AP_P_LAUNCH(D)                                                                                                        \
   resblock_bf16p_kernel<D><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, \
                                                            b2_off, L, d, accumulate, ntiles, nblk)
+#define AP_P_LAUNCH_WIN(D, W)                                                                                                 \
+  resblock_bf16p_kernel<D, W><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,  \
+                                                              b1_off, b2_off, L, d, accumulate, ntiles, nblk)
 #ifdef AP_TOOLS
-  if (ua) {
-    resblock_bf16p_kernel<0, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off,
-                                                               b2_off, L, d, accumulate, ntiles, nblk);
+  if (ws >= 0 && !(g_dbg_bf16 & 0x10000)) {                      // tools bit 0x10000: three-tap staging for every d (A/B)
+    if (ws == 0) AP_P_LAUNCH_WIN(0, 0);
+    else if (ws == 1) AP_P_LAUNCH_WIN(0, 1);
+    else AP_P_LAUNCH_WIN(0, 2);
+  } else if (ws > 0) {
+    return 1;                                                    // d = 1, 2 without the window: the per-tile kernel
   } else
   switch (g_dbg_bf16 & 0xefff) {
     case 0: AP_P_LAUNCH(0); break;
@@ -750,11 +795,13 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     default: set_error("no such DBG instantiation"); return -22;
   }
 #else
-  if (ua) resblock_bf16p_kernel<0, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,
-                                                                     b1_off, b2_off, L, d, accumulate, ntiles, nblk);
+  if (ws == 0) AP_P_LAUNCH_WIN(0, 0);
+  else if (ws == 1) AP_P_LAUNCH_WIN(0, 1);
+  else if (ws == 2) AP_P_LAUNCH_WIN(0, 2);
   else AP_P_LAUNCH(0);
 #endif
 #undef AP_P_LAUNCH
+#undef AP_P_LAUNCH_WIN
   AP_HIP(hipGetLastError());
   return 0;
 }
