@@ -396,10 +396,33 @@ class NativeConvNet(nn.Module):
         torch.cuda.synchronize(dev)
         self._dev_weights, self._packed, self._dev = W, packed, dev
 
-    @N.on_device
+    _foreign = False                           # set when a lazily lowered module turns out not to be a ConvNet this library knows
+
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("NativeConvNet: inference only (BatchNorm folded); call .eval()")
+        """A module that ``lower_classifier`` wrapped on sight (``input_chw=None``) is only KNOWN to contain Conv2d layers.
+        What the reference's scripts would have done with it stays possible: in ``train()`` mode (BatchNorm statistics
+        live: nothing to fold), on CPU with CPU parameters, or once its trace meets an operator the library has no
+        kernel for, the caller's own module runs as it is -- said once, never silently mixed with the native path.
+        An explicitly constructed ``NativeConvNet(module, chw)`` lowers in ``__init__`` and raises there instead."""
+        if self._foreign or self.training:
+            return self.module(x)
+        if not x.is_cuda and self.plan is None and all(not p.is_cuda for p in self.module.parameters()):
+            return self.module(x)
+        return self._forward_native(x)
+
+    @N.on_device
+    def _forward_native(self, x):
+        if self.plan is None and x.is_cuda and x.dim() == 4:     # deferred lowering (input_chw=None)
+            try:
+                self.input_chw = tuple(x.shape[1:])
+                self.plan = lower(self.module, self.input_chw)
+                self._dev_weights = None
+            except NotImplementedError as e:
+                import warnings
+                warnings.warn(f"{type(self.module).__name__}: not lowered onto the HIP library ({e}); the module runs as "
+                              "the caller built it (PyTorch operators)", RuntimeWarning, stacklevel=3)
+                self._foreign, self.plan, self.input_chw = True, None, None
+                return self.module(x)
         if torch.is_grad_enabled() and x.requires_grad:
             return _ConvNetInputGrad.apply(x, self)              # white-box attack: dL/dx (parameters frozen)
         return self._run(x)[0]

@@ -9,6 +9,8 @@ kws_adaptive_attack_eval.py:64-66), so "scripts unchanged" means those objects a
 * a module called ``KWSModel`` with ``CRNN_model / attn_layer / apply_attn`` (RCNN_KWS/model.py:66-90) -> native ``KWSModel``
 * any other module that contains ``nn.Conv2d`` layers (VGG / ResNet / WRN / ResNeXt / DPN / DenseNet pickles)
                                                                                               -> ``NativeConvNet(module)``
+  (lowered at its first input; a module whose trace meets an operator without a kernel, one left in ``train()`` mode, or a
+  CPU module given CPU input keeps running as the caller built it -- ``NativeConvNet.forward`` says so once)
 * ``Compose([MelSpectrogram(n_fft=2048, hop_length=512, n_mels, norm='slaney', pad_mode='constant',
   mel_scale='slaney'), AmplitudeToDB('power')])``                                             -> ``MelSpecDB(n_mels)``
 * ``Sequential(MelSpectrogram(sample_rate=16000, n_mels), AmplitudeToDB('power'))`` (torchaudio defaults: n_fft 400,
@@ -86,8 +88,21 @@ def _mel_signature(mel):
         power = float(getattr(mel, "power", 2.0) or 0.0)
         sr = int(getattr(mel, "sample_rate", 16000))
         win = int(getattr(mel, "win_length", n_fft) or n_fft)
+        # everything else the kernels fix: the full band [0, sr/2], centred one-sided un-normalised frames, no extra pad,
+        # a periodic Hann window (torchaudio's default window_fn; a registered ``window`` buffer is compared to it)
+        f_min = float(getattr(scale, "f_min", getattr(mel, "f_min", 0.0)) or 0.0)
+        f_max = getattr(scale, "f_max", getattr(mel, "f_max", None))
+        full_band = f_min == 0.0 and (f_max is None or abs(float(f_max) - sr / 2.0) < 1e-6)
+        plain = (bool(getattr(spec, "center", getattr(mel, "center", True)))
+                 and not bool(getattr(spec, "normalized", getattr(mel, "normalized", False)))
+                 and bool(getattr(spec, "onesided", getattr(mel, "onesided", True)))
+                 and int(getattr(spec, "pad", getattr(mel, "pad", 0)) or 0) == 0)
+        window = getattr(spec, "window", None)
+        if isinstance(window, torch.Tensor):
+            plain = plain and window.numel() == win and torch.allclose(window.detach().float().cpu(),
+                                                                         torch.hann_window(win, periodic=True), atol=1e-6)
         return dict(n_fft=n_fft, hop=hop, n_mels=n_mels, norm=norm, mel_scale=mscale, pad_mode=pad_mode, power=power,
-                    sample_rate=sr, win_length=win)
+                    sample_rate=sr, win_length=win, standard=bool(full_band and plain))
     except (AttributeError, TypeError, ValueError):
         return None
 
@@ -109,7 +124,8 @@ def lower_transform(t):
     if st is None or len(st) != 2 or not _is_power_to_db(st[1]):
         return t
     sig = _mel_signature(st[0])
-    if sig is None or sig["power"] != 2.0 or sig["sample_rate"] != 16000 or sig["win_length"] != sig["n_fft"]:
+    if (sig is None or sig["power"] != 2.0 or sig["sample_rate"] != 16000 or sig["win_length"] != sig["n_fft"]
+            or not sig["standard"]):                                         # f_max = 4000, center = False, ...: not ours
         return t
     if (sig["n_fft"], sig["hop"], sig["norm"], sig["mel_scale"], sig["pad_mode"]) == (2048, 512, "slaney", "slaney", "constant"):
         return MelSpecDB(n_mels=sig["n_mels"])                               # adaptive_attack_eval.py:83-85

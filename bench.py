@@ -109,6 +109,39 @@ def self_launch(args, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def rank_evidence(use_dist, elapsed_local, device_desc, backend):
+    """What makes an N > 1 line self-evidencing: the size of the process group the collective backend actually formed
+    (`rccl_ranks` on the GPU path, after the `nccl` init), every rank's own elapsed time for the K timed steps (min / max:
+    `ms_per_step` is the max), and the device each rank bound -- N ranks on N distinct GPUs is visible in the JSON."""
+    import torch.distributed as dist
+    if not use_dist:
+        return {"backend": None, "rccl_ranks" if backend == "nccl" else "ranks": 0, "rank_elapsed_s": [round(elapsed_local, 4)],
+                "rank_elapsed_min_s": round(elapsed_local, 4), "rank_elapsed_max_s": round(elapsed_local, 4),
+                "devices": [device_desc], "distinct_devices": 1}
+    world = dist.get_world_size()
+    objs = [None] * world
+    dist.all_gather_object(objs, {"rank": dist.get_rank(), "elapsed_s": elapsed_local, "device": device_desc})
+    objs.sort(key=lambda o: o["rank"])
+    el = [o["elapsed_s"] for o in objs]
+    devs = [o["device"] for o in objs]
+    return {"backend": dist.get_backend(), "rccl_ranks" if backend == "nccl" else "ranks": world,
+            "rank_elapsed_s": [round(e, 4) for e in el], "rank_elapsed_min_s": round(min(el), 4),
+            "rank_elapsed_max_s": round(max(el), 4), "devices": devs,
+            "distinct_devices": len({d.get("pci_bus_id") or d.get("uuid") or d.get("index") for d in devs})}
+
+
+def device_descriptor(torch, local):
+    """Name + PCI address (+ uuid where torch exposes it) of the HIP device this rank bound."""
+    p = torch.cuda.get_device_properties(local)
+    d = {"index": local, "name": torch.cuda.get_device_name(local)}
+    dom, bus, devid = (getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    if bus is not None:
+        d["pci_bus_id"] = f"{(dom or 0):04x}:{bus:02x}:{(devid or 0):02x}"
+    if getattr(p, "uuid", None) is not None:
+        d["uuid"] = str(p.uuid)
+    return d
+
+
 def dry_run(args) -> None:
     """CPU rehearsal of the multi-rank protocol (gloo): shard bounds, barrier, the scores all_gather, max-over-ranks
     timing, one JSON line from rank 0.  No kernel runs and `value` is not a throughput."""
@@ -137,6 +170,7 @@ def dry_run(args) -> None:
     if use_dist:
         dist.barrier()
     el = time.perf_counter() - t0
+    ranks = rank_evidence(use_dist, el, {"index": rank, "name": "cpu (dry run)", "pci_bus_id": f"cpu:{rank}"}, "gloo")
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -147,6 +181,7 @@ def dry_run(args) -> None:
                           "value": None, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(el * 1e3 / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": args.precision, "data": "none (protocol rehearsal on CPU, gloo)",
+                          "ranks": ranks,
                           "config": {"workload": "dry run: launcher + sharding + scores all_gather only",
                                      "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, logits all_gather"}}),
               flush=True)
@@ -306,6 +341,7 @@ def main():
         N.check(eng.lib.ap_profile_read(eng.ctx, C.byref(tot_ms), C.byref(launches)))
         N.check(eng.lib.ap_profile_enable(eng.ctx, 0))
         assert torch.isfinite(lp).all()
+        run_mode.local_elapsed = elapsed                          # this rank's own clock, before the max over ranks
         if use_dist:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,7 +375,7 @@ def main():
                     "executed_f16_TFLOPs": round(3 * achieved, 1)}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "resblock_bf16p_kernel (persistent; layers with d = 1, 2: resblock_bf16_kernel<256>)", "achieved": round(gbs, 1), "peak": 8000.0,
+            roof = {"bound": "hbm", "kernel": "resblock_bf16p_kernel (persistent, every dilation)", "achieved": round(gbs, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic,
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
         roof.update({"traffic_source": traffic_source, "launches": launches, "avg_launch_ms": round(k_ms, 4),
@@ -349,6 +385,7 @@ def main():
         return roof
 
     elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
+    ranks = rank_evidence(use_dist, run_mode.local_elapsed, device_descriptor(torch, local), "nccl")
     # the other arithmetic modes of the same path, measured in the same run (N = 1 only: they are extra evidence,
     # not the headline): same inputs, same chain, same timing brackets
     others = {}
@@ -393,6 +430,7 @@ def main():
                        "global_batch": world * B, "clip_samples": L, "reverse_steps": n,
                        "parallelism": f"utterance-sharded x{world}, logits all_gather"},
             "roofline": roof,
+            "ranks": ranks,
         }
         if others:
             out["other_modes"] = others

@@ -133,7 +133,8 @@ def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict
             taps[f"h{n}"] = h
             taps[f"skip{n}"] = skip
     y = skip * math.sqrt(1.0 / N)                                                        # :135
-    y = F.conv1d(y, w["final_conv.0.conv.weight"], w["final_conv.0.conv.bias"])          # :160
+    q = _bf16 if bf16_operands else (lambda t: t)      # bf16 mode: final_conv's S -> S 1x1 runs on the bf16 pipe as well
+    y = F.conv1d(q(y), q(w["final_conv.0.conv.weight"]), w["final_conv.0.conv.bias"])    # :160
     y = F.relu(y)                                                                        # :161
     return F.conv1d(y, w["final_conv.2.conv.weight"], w["final_conv.2.conv.bias"])       # :162
 
@@ -150,20 +151,21 @@ def q_sample(dh: dict, x0: torch.Tensor, t_star: int, z: torch.Tensor) -> torch.
     return torch.sqrt(ab) * x0 + torch.sqrt(1 - ab) * z                                  # :67
 
 
-def ddpm_coefficients(w, cfg, dh, x, t: int):
-    eps = eps_net(w, cfg, x, _steps(x.shape[0], t))                                      # :157-158
+def ddpm_coefficients(w, cfg, dh, x, t: int, bf16_operands: bool = False):
+    eps = eps_net(w, cfg, x, _steps(x.shape[0], t), bf16_operands=bf16_operands)         # :157-158
     A, Ab = dh["Alpha"], dh["Alpha_bar"]
     mu = (x - (1 - A[t]) / torch.sqrt(1 - Ab[t]) * eps) / torch.sqrt(A[t])               # :159
     return eps, mu, dh["Sigma"][t]                                                       # :160
 
 
-def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list) -> torch.Tensor:
-    """``DiffWave.forward`` with injected noise: noises[0] = q-sample z, noises[k] = k-th reverse draw."""
+def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list, bf16_operands: bool = False) -> torch.Tensor:
+    """``DiffWave.forward`` with injected noise: noises[0] = q-sample z, noises[k] = k-th reverse draw.
+    ``bf16_operands``: every eps-evaluation of the chain emulates the AP_PREC_BF16 mode (see ``residual_block``)."""
     with torch.no_grad():
         x = q_sample(dh, x0, t_star, noises[0])
         k = 1
         for t in range(t_star - 1, -1, -1):                                              # :95
-            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t)
+            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t, bf16_operands)
             if t > 0:
                 x = mu + sigma * noises[k]                                               # :100
                 k += 1
@@ -242,14 +244,15 @@ def sde_tables(T: int = 200, beta_0: float = 0.0001, beta_T: float = 0.02) -> di
             "sqrt_1m_alphas_cumprod": torch.sqrt(1.0 - ac)}
 
 
-def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int):
+def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int, bf16_operands: bool = False):
     """Drift f and diffusion g of the REVERSE SDE in torchsde time at discrete index k
     (= ``RevVPSDE.f`` / ``.g`` with ``disc_steps = k``; :73-134)."""
     N = tb["N"]
     beta_t = tb["discrete_betas"][k] * N                                                 # :77
     drift = -0.5 * beta_t * x                                                            # :79
     diffusion = torch.sqrt(beta_t)                                                       # :80
-    eps = eps_net(w, cfg, x.view(x.shape[0], 1, -1), _steps(x.shape[0], k)).view(x.shape[0], -1)   # :95-97
+    eps = eps_net(w, cfg, x.view(x.shape[0], 1, -1), _steps(x.shape[0], k),
+                  bf16_operands=bf16_operands).view(x.shape[0], -1)                      # :95-97
     score = -eps / tb["sqrt_1m_alphas_cumprod"][k]                                       # :99
     drift = drift - diffusion ** 2 * score                                               # :104
     if k > 0:
@@ -259,7 +262,8 @@ def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int):
     return -drift, scale * diffusion                                                     # :125, :114, :134
 
 
-def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list, q_level: int | None = None) -> torch.Tensor:
+def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list, q_level: int | None = None,
+               bf16_operands: bool = False) -> torch.Tensor:
     """``RevDiffWave.audio_editing_sample`` (sample_step = 1) with torchsde's Euler scheme
     ``y <- y + f h + g sqrt(h) z`` restated (torchsde 0.2.5, un-vendored: parity unpinned for
     the loop itself).  h = 1/N; steps k = t*-1 ... 0: exactly t* eps-evaluations (the reference's
@@ -274,7 +278,7 @@ def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list, q_
         y = x.view(x.shape[0], -1)
         h = 1.0 / N
         for i, k in enumerate(range(t_star - 1, -1, -1)):
-            f, g = sde_f_g(w, cfg, tb, y, k)
+            f, g = sde_f_g(w, cfg, tb, y, k, bf16_operands)
             y = y + f * h + g * math.sqrt(h) * noises[1 + i].view(y.shape)
         return y.view(x.shape)
 

@@ -97,3 +97,42 @@ def test_restated_models_have_reference_state_dict_keys():
     assert list(vgg19_bn(10, 1).state_dict().keys()) == list(g["vgg19_bn/keys"])
     assert list(CifarResNeXt(10).state_dict().keys()) == list(g["resnext29_8_64/keys"])
     assert sum(p.numel() for p in CifarResNeXt(10).parameters()) == 34425546
+
+
+def test_mel_front_end_with_other_band_or_framing_is_left_alone():
+    """lower_transform only replaces the exact pipelines the kernels implement (adaptive_attack_eval.py:83-85,
+    kws_adaptive_attack_eval.py:64-66): a different band, framing or normalisation stays the caller's module."""
+    import fake_torchaudio as ta
+    from audiopure_amd.lowering import lower_transform
+    from audiopure_amd.transforms.melspec import MelSpecDB
+
+    def pipe(**kw):
+        a = dict(n_fft=2048, hop_length=512, n_mels=32, norm="slaney", pad_mode="constant", mel_scale="slaney")
+        a.update(kw)
+        return ta.Compose([ta.MelSpectrogram(**a), ta.AmplitudeToDB(stype="power")])
+
+    assert type(lower_transform(pipe())) is MelSpecDB
+    assert type(lower_transform(pipe(f_max=8000.0))) is MelSpecDB
+    for kw in (dict(f_max=4000.0), dict(f_min=50.0), dict(center=False), dict(normalized=True), dict(onesided=False),
+               dict(pad=16)):
+        t = pipe(**kw)
+        assert lower_transform(t) is t, kw
+
+
+def test_lazily_wrapped_module_keeps_the_callers_semantics_off_the_native_path():
+    """lower_classifier wraps any Conv2d-bearing module on sight; in train() mode and on CPU (CPU parameters, CPU input)
+    the wrapper runs the module itself, as the reference's scripts would have (acoustic_system.py:35-51)."""
+    import torch
+    import torch.nn as nn
+    from audiopure_amd.convnet import NativeConvNet
+    from audiopure_amd.lowering import lower_classifier
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Conv2d(1, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+                      nn.Linear(4, 3))
+    x = torch.randn(2, 1, 8, 8)
+    w = lower_classifier(m.train())
+    assert isinstance(w, NativeConvNet) and w.training
+    assert w(x).shape == (2, 3)                                               # train mode: the module itself (BN batch stats)
+    w.eval()
+    with torch.no_grad():
+        assert torch.equal(w(x), m(x))                                        # CPU module + CPU input: the module itself

@@ -95,3 +95,41 @@ def test_acoustic_system_dispatch_order():
     AcousticSystem(Rec("cls"), Rec("tr"), Rec("def"), "spec")(torch.zeros(1), True)
     AcousticSystem(Rec("cls"), None, Rec("def"), "wave")(torch.zeros(1), False)
     assert calls == ["def", "tr", "cls", "tr", "def", "cls", "cls"]      # acoustic_system.py:35-51
+
+
+def test_script_constructors_read_json_config_and_pkl_checkpoint(tmp_path):
+    """The constructors the eval scripts call (diffwave_ddpm.py:395-411, diffwave_sde.py:138-161) on files written in the
+    reference's formats -- JSON with wavenet_config / diffusion_config, .pkl with model_state_dict -- generated from synth
+    (nothing of the reference's is read).  CPU: construction and parsing only; the forward needs the GPU
+    (tests/test_gpu_dropin.py runs both constructors end to end)."""
+    import argparse
+    import json
+
+    import torch
+
+    from audiopure_amd import synth
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave, create_diffwave_model
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    sd = synth.wavenet_state_dict(cfg, 0)
+    ckpt, conf = tmp_path / "1000000.pkl", tmp_path / "config.json"
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in sd.items()}, "optimizer_state_dict": {}}, str(ckpt))
+    conf.write_text(json.dumps({"wavenet_config": cfg, "diffusion_config": dict(synth.DIFFUSION_CONFIG)}))
+    dw = create_diffwave_model(str(ckpt), str(conf), reverse_timestep=25, device=torch.device("cpu"))
+    assert isinstance(dw, DiffWave) and dw.reverse_timestep == 25
+    assert sum(p.numel() for p in dw.model.parameters()) == 24071681
+    got = dw.model.state_dict()
+    assert set(got) == set(sd)
+    for k in ("init_conv.0.conv.weight_g", "residual_layer.residual_blocks.35.skip_conv.weight_v", "final_conv.2.conv.weight"):
+        assert torch.equal(got[k], torch.from_numpy(sd[k])), k
+    assert float(dw.diffusion_hyperparams["Sigma"][0]) == pytest.approx(0.01)
+    args = argparse.Namespace(ddpm_path=str(ckpt), ddpm_config=str(conf), t=4, score_type="guided_diffusion", rand_t=False,
+                              t_delta=0, use_bm=False, sample_step=1)
+    rev = RevDiffWave(args, device=torch.device("cpu"))
+    assert rev._get_name() == "RevDiffWave" and rev.model.reverse_timestep == 4 and rev.T == 200
+    assert rev.rev_vpsde.noise_type == "diagonal" and rev.rev_vpsde.sde_type == "ito"
+    rev.rev_vpsde.audio_shape = (1, 8000)                                      # writable, as the scripts do
+    with pytest.raises(KeyError):
+        bad = tmp_path / "bad.pkl"
+        torch.save({"state_dict": {}}, str(bad))
+        create_diffwave_model(str(bad), str(conf), device=torch.device("cpu"))

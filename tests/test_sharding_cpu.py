@@ -73,3 +73,9 @@ def test_bench_self_launches_its_ranks_as_children_and_prints_one_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+    # the self-evidencing fields of an N > 1 line: group size as the backend formed it, per-rank clocks, per-rank devices
+    rk = out["ranks"]
+    assert rk["backend"] == "gloo" and rk["ranks"] == 2 and rk["distinct_devices"] == 2
+    assert len(rk["rank_elapsed_s"]) == 2 and rk["rank_elapsed_min_s"] <= rk["rank_elapsed_max_s"]
+    assert [d["index"] for d in rk["devices"]] == [0, 1]
+    assert out["ms_per_step"] * out["steps"] >= rk["rank_elapsed_min_s"] * 1e3 * 0.5
