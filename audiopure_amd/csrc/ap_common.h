@@ -140,6 +140,8 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
                          int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);   // persistent form; returns 1 if the shape is not served
+int launch_resblock_bf16w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
+                          int accumulate, int B, int L, hipStream_t st);   // one wave per SIMD; returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
 int launch_pack_splith(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,

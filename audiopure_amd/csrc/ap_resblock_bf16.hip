@@ -678,6 +678,14 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
   if (!force_tile && !g_trace_bf16)
 #endif
   {
+#ifdef AP_TOOLS
+    // tools builds only: the one-wave-per-SIMD experiment (ap_resblock_bf16w.hip; bit-identical, 20 % slower: DESIGN.md 3.4)
+    // serves the launch when bit 0x20000 asks for it -- tools/ab_bf16w.py, ablate_bf16w.py, trace_resblock_bf16w.py
+    if (g_dbg_bf16 & 0x20000) {
+      const int rcw = launch_resblock_bf16w(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+      if (rcw != 1) return rcw;                                  // 1: shape not served there -> the eight-wave persistent kernel
+    }
+#endif
     const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
     if (rc != 1) return rc;                                      // 1: shape not served there (L % 4, C, S) -> per-tile kernel
   }
