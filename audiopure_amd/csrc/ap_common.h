@@ -23,7 +23,7 @@ int hip_fail(hipError_t e, const char *what);
   } while (0)
 
 // Timing-only hooks (ablation masks, phase stamps, dispatch overrides: tools/*.py) exist only in a -DAP_TOOLS build
-// (`python __graft_entry__.py --tools` -> lib/libaudiopure_hip_tools.so).  The shipped library has no `ablate` kernel
+// (`python __graft_entry__.py --tools` -> tools/lib/libaudiopure_hip_tools.so).  The shipped library has no `ablate` kernel
 // argument, no ap_debug_* symbol and no stamped instantiation.
 #ifdef AP_TOOLS
 #define AP_ABLATE_PARAM , int ablate

@@ -32,74 +32,7 @@ __device__ __forceinline__ float gate_fast(float a, float b) {
   return (1.0f - E) * __builtin_amdgcn_rcpf((1.0f + E) * (1.0f + F));
 }
 
-// ---- weight images -------------------------------------------------------------------------------------------
-// GEMM1: [wave C/32][chunk C/32][kstep 6][rowtile 2][lane 64][8]; wave w owns gate channels [32w, 32w+32):
-// row tile 0 = tanh rows, 1 = sigmoid rows; k-step ks of a chunk = tap ks/2, channels ch*32 + (ks&1)*16 + 8h + jj.
-__global__ void pack_w1_bf16_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out, int C) {
-  const int NW = C / 32, NCH = C / BKC;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)NW * NCH * 6 * 2 * 64 * 8;
-  if (idx >= total) return;
-  int jj = idx & 7;
-  int lane = (idx >> 3) & 63;
-  int rt = (idx >> 9) & 1;
-  size_t rest = idx >> 10;
-  int ks = rest % 6; rest /= 6;
-  int ch = rest % NCH;
-  int w = rest / NCH;
-  int i = lane & 31, hh = lane >> 5;
-  int tap = ks >> 1;
-  int c = ch * BKC + (ks & 1) * 16 + 8 * hh + jj;
-  int o = rt * C + 32 * w + i;
-  out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + tap];
-}
-
-// GEMM2: [wave][rowtile 2][kstep C/16][lane][8]; row tile 0 = res_conv rows of the wave's channels, 1 = skip rows.
-__global__ void pack_w2_bf16_kernel(const float *__restrict__ w2f, __bf16 *__restrict__ out, int C) {
-  const int NW = C / 32, NKS = C / 16;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t total = (size_t)NW * NKS * 2 * 64 * 8;
-  if (idx >= total) return;
-  int jj = idx & 7;
-  int lane = (idx >> 3) & 63;
-  size_t rest = idx >> 9;
-  int ks = rest % NKS; rest /= NKS;
-  int rt = rest & 1;
-  int w = rest >> 1;
-  int i = lane & 31, hh = lane >> 5;
-  int k = ks * 16 + 8 * hh + jj;
-  int o = rt * C + 32 * w + i;          // w2f = [res rows (C); skip rows (C)]
-  out[idx] = (__bf16)w2f[(size_t)o * C + k];
-}
-
-// final conv's first 1x1: [wave S/64][rowtile 2][kstep S/16][lane 64][8]; wave w owns output rows [64w, 64w+64)
-__global__ void pack_wf1_bf16_kernel(const float *__restrict__ wf1f, __bf16 *__restrict__ out, int S) {
-  const int NKS = S / 16;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)S * S) return;
-  int jj = idx & 7;
-  int lane = (idx >> 3) & 63;
-  size_t rest = idx >> 9;
-  int ks = rest % NKS; rest /= NKS;
-  int rt = rest & 1;
-  int w = rest >> 1;
-  int k = ks * 16 + 8 * (lane >> 5) + jj;
-  int o = 64 * w + 32 * rt + (lane & 31);
-  out[idx] = (__bf16)wf1f[(size_t)o * S + k];
-}
-
-int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
-  const int C = ctx->C, S = ctx->S, NL = ctx->NL;
-  for (int n = 0; n < NL; n++) {
-    size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
-    pack_w1_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1p_bf + n * n1, C);
-    pack_w2_bf16_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, (__bf16 *)ctx->w2p_bf + n * n2, C);
-  }
-  if (ctx->wf1p_bf && S % 64 == 0)
-    pack_wf1_bf16_kernel<<<(unsigned)(((size_t)S * S + 255) / 256), 256, 0, st>>>(ctx->wf1f, (__bf16 *)ctx->wf1p_bf, S);
-  AP_HIP(hipGetLastError());
-  return 0;
-}
+// (weight images: pack_w*_bf16_kernel / launch_pack_bf16 live in ap_resblock_bf16p.hip, the product file)
 
 // ---- the kernel ---------------------------------------------------------------------------------------------
 // What bounds it (tools/trace_resblock_bf16.py, s_memtime stamps per phase): the CU's one vector-memory address

@@ -71,6 +71,75 @@ using I3 = std::integral_constant<int, 3>;
 
 }  // namespace
 
+// ---- weight images -------------------------------------------------------------------------------------------
+// GEMM1: [wave C/32][chunk C/32][kstep 6][rowtile 2][lane 64][8]; wave w owns gate channels [32w, 32w+32):
+// row tile 0 = tanh rows, 1 = sigmoid rows; k-step ks of a chunk = tap ks/2, channels ch*32 + (ks&1)*16 + 8h + jj.
+__global__ void pack_w1_bf16_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out, int C) {
+  const int NW = C / 32, NCH = C / KC_;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)NW * NCH * 6 * 2 * 64 * 8;
+  if (idx >= total) return;
+  int jj = idx & 7;
+  int lane = (idx >> 3) & 63;
+  int rt = (idx >> 9) & 1;
+  size_t rest = idx >> 10;
+  int ks = rest % 6; rest /= 6;
+  int ch = rest % NCH;
+  int w = rest / NCH;
+  int i = lane & 31, hh = lane >> 5;
+  int tap = ks >> 1;
+  int c = ch * KC_ + (ks & 1) * 16 + 8 * hh + jj;
+  int o = rt * C + 32 * w + i;
+  out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + tap];
+}
+
+// GEMM2: [wave][rowtile 2][kstep C/16][lane][8]; row tile 0 = res_conv rows of the wave's channels, 1 = skip rows.
+__global__ void pack_w2_bf16_kernel(const float *__restrict__ w2f, __bf16 *__restrict__ out, int C) {
+  const int NW = C / 32, NKS = C / 16;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)NW * NKS * 2 * 64 * 8;
+  if (idx >= total) return;
+  int jj = idx & 7;
+  int lane = (idx >> 3) & 63;
+  size_t rest = idx >> 9;
+  int ks = rest % NKS; rest /= NKS;
+  int rt = rest & 1;
+  int w = rest >> 1;
+  int i = lane & 31, hh = lane >> 5;
+  int k = ks * 16 + 8 * hh + jj;
+  int o = rt * C + 32 * w + i;          // w2f = [res rows (C); skip rows (C)]
+  out[idx] = (__bf16)w2f[(size_t)o * C + k];
+}
+
+// final conv's first 1x1: [wave S/64][rowtile 2][kstep S/16][lane 64][8]; wave w owns output rows [64w, 64w+64)
+__global__ void pack_wf1_bf16_kernel(const float *__restrict__ wf1f, __bf16 *__restrict__ out, int S) {
+  const int NKS = S / 16;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)S * S) return;
+  int jj = idx & 7;
+  int lane = (idx >> 3) & 63;
+  size_t rest = idx >> 9;
+  int ks = rest % NKS; rest /= NKS;
+  int rt = rest & 1;
+  int w = rest >> 1;
+  int k = ks * 16 + 8 * (lane >> 5) + jj;
+  int o = 64 * w + 32 * rt + (lane & 31);
+  out[idx] = (__bf16)wf1f[(size_t)o * S + k];
+}
+
+int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
+  const int C = ctx->C, S = ctx->S, NL = ctx->NL;
+  for (int n = 0; n < NL; n++) {
+    size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
+    pack_w1_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1p_bf + n * n1, C);
+    pack_w2_bf16_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, (__bf16 *)ctx->w2p_bf + n * n2, C);
+  }
+  if (ctx->wf1p_bf && S % 64 == 0)
+    pack_wf1_bf16_kernel<<<(unsigned)(((size_t)S * S + 255) / 256), 256, 0, st>>>(ctx->wf1f, (__bf16 *)ctx->wf1p_bf, S);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
 #ifdef AP_TOOLS
 __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [workgroup][wave][64] s_memtime stamps of one tile
 #endif
@@ -79,7 +148,11 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // 8 no GEMM1 MFMA, 16 no B-fragment LDS reads, 32 no gate math, 64 no GEMM2 MFMA, 128 no read-modify-write loads,
 // 256 no stores, 512 no per-chunk barrier, 1024 every tile stages the same 128 columns of clip 0, 2048 phase stamps, 0x2000 no priority swap,
 // 0x4000 default cache policy instead of nt (exact), 0x8000 contiguous walk inside a clip for every dilation (exact).
-template <int DBG, int WS = -1>              // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
+// RAG: clip lengths that are not a multiple of four.  Channel rows are then only 4-byte aligned (16-byte accesses at 4-byte
+// aligned addresses are exact on this chip: tools/micro/unaligned_b128.hip), the clip's last column quad is partly outside
+// it: staged samples are zeroed one by one (the quad's count of valid samples instead of one mask), and the epilogue stores
+// of that quad are one to three dwords.
+template <int DBG, int WS = -1, bool RAG = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
@@ -200,13 +273,23 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     if constexpr (WIN) {
       const int tq = t0 - 32 + 4 * (min(wave, 5) * 8 + (ln >> 3));
-      k.m[0] = (tq >= 0 && tq < L) ? 0xffffffffu : 0u;
-      voff = ((unsigned)min(max(tq, 0), L - 4) + (unsigned)((ln & 7) * 4) * (unsigned)L) * 4u;
+      if constexpr (RAG) {                                       // (tq < 0: the whole quad is outside -- tile starts and the window's
+        k.m[0] = tq >= 0 ? (unsigned)min(max(L - tq, 0), 4) : 0u;     //  left edge are multiples of four)
+        voff = ((unsigned)min(max(tq, 0), L - 1) + (unsigned)((ln & 7) * 4) * (unsigned)L) * 4u;
+      } else {
+        k.m[0] = (tq >= 0 && tq < L) ? 0xffffffffu : 0u;
+        voff = ((unsigned)min(max(tq, 0), L - 4) + (unsigned)((ln & 7) * 4) * (unsigned)L) * 4u;
+      }
     } else {
       const int cg = ((wave & 1) * 4 + (ln >> 4)) * 4 + (ln & 3), oct = (ln >> 2) & 3;
       const int tp = t0 + 4 * cg + (xtap - 1) * d;
-      k.m[0] = (tp >= 0 && tp < L) ? 0xffffffffu : 0u;
-      voff = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+      if constexpr (RAG) {
+        k.m[0] = tp >= 0 ? (unsigned)min(max(L - tp, 0), 4) : 0u;
+        voff = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+      } else {
+        k.m[0] = (tp >= 0 && tp < L) ? 0xffffffffu : 0u;
+        voff = ((unsigned)min(max(tp, 0), L - 4) + (unsigned)(oct * 8) * (unsigned)L) * 4u;
+      }
     }
   };
   const __amdgpu_buffer_rsrc_t hrs_clip0 = clip_rsrc(hin, 0);
@@ -251,6 +334,8 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   auto pack_piece = [&](unsigned char *dst, const Keep &keep, auto i_tag, auto hf_tag) {
     constexpr int i = decltype(i_tag)::value, hf = decltype(hf_tag)::value;
     if constexpr (DBG & 4) return;
+    // RAG: keep.m[0] counts the quad's valid samples -> all ones for sample i iff i < count
+    const unsigned km = RAG ? (unsigned)(((int)i - (int)keep.m[0]) >> 31) : keep.m[0];
     if constexpr (WIN) {
       if (wave < 6) {                                            // wave-uniform
         if constexpr (hf == 0) {
@@ -258,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           for (int e2 = 0; e2 < 2; e2++)
             pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
                                                        f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
-                                                             xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep.m[0];
+                                                             xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & km;
         } else {
 #pragma unroll
           for (int T = 0; T < 3; T++) {
@@ -274,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       for (int e2 = 2 * hf; e2 < 2 * hf + 2; e2++)
         pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
                                                    f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
-                                                         xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & keep.m[0];
+                                                         xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & km;
       if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS_ + xk) * 2) = pkq;
     }
   };
@@ -656,7 +741,17 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           // row step in the VGPR offset, soffset = 0: a >8-byte buffer store with an SGPR soffset reads its data late and
           // the compiler does not guard the next write of those VGPRs (observed in round 1: torn lanes)
           if constexpr (DBG & 256) asm volatile("" ::"v"(o));
-          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst, evoff[ct] + (unsigned)(8 * p * L * 4), 0, NT);
+          else if constexpr (RAG) {
+            const int nv = L - (t0 + 32 * ct + 4 * (lane & 7));  // valid samples of this lane's column quad (>= 4: all)
+            const unsigned so = evoff[ct] + (unsigned)(8 * p * L * 4);
+            const u32x4 ou = __builtin_bit_cast(u32x4, o);       // (whole-vector bit_cast: element-wise it is mis-folded to a splat)
+            if (nv >= 4) __builtin_amdgcn_raw_buffer_store_b128(ou, dst, so, 0, NT);
+            else {
+              if (nv >= 1) __builtin_amdgcn_raw_buffer_store_b32(ou[0], dst, so, 0, NT);
+              if (nv >= 2) __builtin_amdgcn_raw_buffer_store_b32(ou[1], dst, so + 4u, 0, NT);
+              if (nv >= 3) __builtin_amdgcn_raw_buffer_store_b32(ou[2], dst, so + 8u, 0, NT);
+            }
+          } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst, evoff[ct] + (unsigned)(8 * p * L * 4), 0, NT);
         }
       }
     };
@@ -713,7 +808,8 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
                           int B, int L, hipStream_t st) {
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
-  if (C != 256 || S != 256 || (L % 4) != 0 || L < 4) return 1;
+  if (C != 256 || S != 256 || L < 1) return 1;
+  const bool rag = (L % 4) != 0;                                 // ragged clip length: the RAG instantiations
   // staging form: one window for the three taps where they overlap (d <= 32), else three tap loads
   const int ws = d == 1 ? 1 : d == 2 ? 2 : (d <= 32 && d % 4 == 0) ? 0 : d < 4 ? -2 : -1;
   if (ws == -2) return 1;                                        // (d = 3: no such dilation in a power-of-two cycle)
@@ -745,7 +841,15 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 #define AP_P_LAUNCH_WIN(D, W)                                                                                                 \
   resblock_bf16p_kernel<D, W><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,  \
                                                               b1_off, b2_off, L, d, accumulate, ntiles, nblk)
+#define AP_P_LAUNCH_RAG(W)                                                                                                    \
+  resblock_bf16p_kernel<0, W, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, \
+                                                                    b1_off, b2_off, L, d, accumulate, ntiles, nblk)
 #ifdef AP_TOOLS
+  if (rag) {
+    if (ws == 1) AP_P_LAUNCH_RAG(1);
+    else if (ws == 2) AP_P_LAUNCH_RAG(2);
+    else AP_P_LAUNCH_RAG(-1);
+  } else
   if (ws >= 0 && !(g_dbg_bf16 & 0x10000)) {                      // tools bit 0x10000: three-tap staging for every d (A/B)
     if (ws == 0) AP_P_LAUNCH_WIN(0, 0);
     else if (ws == 1) AP_P_LAUNCH_WIN(0, 1);
@@ -795,15 +899,39 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     default: set_error("no such DBG instantiation"); return -22;
   }
 #else
-  if (ws == 0) AP_P_LAUNCH_WIN(0, 0);
+  if (rag) {                                                     // (d = 4 .. 32 ragged: the three-tap form, one instantiation fewer)
+    if (ws == 1) AP_P_LAUNCH_RAG(1);
+    else if (ws == 2) AP_P_LAUNCH_RAG(2);
+    else AP_P_LAUNCH_RAG(-1);
+  } else if (ws == 0) AP_P_LAUNCH_WIN(0, 0);
   else if (ws == 1) AP_P_LAUNCH_WIN(0, 1);
   else if (ws == 2) AP_P_LAUNCH_WIN(0, 2);
   else AP_P_LAUNCH(0);
 #endif
 #undef AP_P_LAUNCH
 #undef AP_P_LAUNCH_WIN
+#undef AP_P_LAUNCH_RAG
   AP_HIP(hipGetLastError());
   return 0;
 }
+
+#ifndef AP_TOOLS
+// AP_PREC_BF16 dispatch of the product library: the persistent kernel serves every shape of the supported configuration
+// (C = S = 256; any dilation of a power-of-two cycle, any clip length).  The one-tile-per-workgroup kernel of round 1
+// (ap_resblock_bf16.hip) is compiled into the tools library only, as the A/B baseline of tools/cmp_bf16_kernels.py.
+int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
+                         int B, int L, hipStream_t st) {
+  if (ctx->C != 256 || ctx->S != 256) {
+    set_error("AP_PREC_BF16 is built for res_channels = skip_channels = 256 only (got %d / %d)", ctx->C, ctx->S);
+    return -22;
+  }
+  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+  if (rc == 1) {
+    set_error("AP_PREC_BF16: shape not served (layer %d, L = %d)", layer, L);
+    return -22;
+  }
+  return rc;
+}
+#endif
 
 }  // namespace ap

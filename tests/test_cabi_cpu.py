@@ -83,3 +83,19 @@ def test_cpu_tensors_are_rejected():
     import torch
     with pytest.raises(N.NativeError):
         N.ptr(torch.zeros(4))
+
+
+def test_product_library_ships_no_tools_kernels_or_debug_hooks():
+    """The shipped library holds the product kernels only: no ap_debug_* hook, neither the round-1 one-tile-per-workgroup bf16
+    block nor the one-wave-per-SIMD experiment (both live in the -DAP_TOOLS library under tools/lib/, which must not sit
+    beside the product library)."""
+    import os
+    import subprocess
+    from audiopure_amd import _native as N
+    libdir = os.path.dirname(N.LIB_PATH)
+    assert [f for f in os.listdir(libdir) if f.endswith(".so")] == ["libaudiopure_hip.so"]
+    sym = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "ap_debug_" not in sym
+    for name in ("resblock_bf16_kernel", "resblock_bf16w_kernel"):
+        assert name not in sym, name
+    assert "resblock_bf16p_kernel" in sym

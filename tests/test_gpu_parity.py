@@ -484,6 +484,31 @@ def test_bf16_full_chain_matches_bf16_emulating_chain_oracle_and_fp32_reference(
     assert err_f < TOL_BF16_VS_FP32
 
 
+@pytest.mark.parametrize("L", [23457, 5003, 1001])
+def test_bf16_eps_on_variable_length_clips_meets_the_bf16_oracle(dev, L):
+    """Clips that are not 1 s and not a multiple of four samples (kws_adaptive_attack_eval.py:178 sets audio_shape per
+    utterance) in bf16 mode: all twelve dilations of a cycle through the persistent kernel's ragged instantiations, against
+    the oracle network with the same operand roundings.  Stated tolerance for one eps-evaluation in this mode: 1e-2 of
+    max|eps| (bf16 rounding-boundary flips of u and g, 2^-9 each, through twelve layers and final_conv); the ragged length
+    must do no worse than the next multiple of four, which runs the aligned instantiations, by more than a factor 1.5."""
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=5)
+    net.set_precision("bf16")
+    w = O.fold_state_dict(sd)
+    errs = []
+    for Lx in (L, L + 4 - L % 4):
+        x = torch.from_numpy(synth.waveforms(2, Lx, seed=L))
+        got = net.eps(x.to(dev), 3.0).cpu()
+        with torch.no_grad():
+            ref = O.eps_net(w, cfg, x, 3.0 * torch.ones(2, 1), bf16_operands=True)
+        assert got.shape == ref.shape
+        errs.append(rel_err(got.numpy(), ref.numpy()))
+    print("bf16 eps rel err ragged / aligned:", errs)
+    assert errs[0] < 1e-2 and errs[1] < 1e-2
+    assert errs[0] < 1.5 * errs[1] + 1e-3
+
+
 # ---- direct C-ABI entry points, chunking, graph capture ---------------------------------------------------------
 # ---- AP_PREC_F32_SPLIT: fp32 operands as three bf16 parts, six partial products on the bf16 MFMA ------------------
 @pytest.mark.parametrize("L,layer", [(1500, 2), (2048, 10), (4133, 11), (130, 3), (16000, 0)])

@@ -8,7 +8,7 @@ from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNe
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 layers = [int(a) for a in sys.argv[2:]] or [0, 1, 2, 9, 11, 12, 13]
-L = 16000
+L = int(_os.environ.get("AP_CMP_L", "16000"))
 torch.manual_seed(0)
 h = torch.randn(B, 256, L, device=dev); sk0 = torch.randn(B, 256, L, device=dev); pt = torch.randn(256, device=dev)
 net = WaveNet_Speech_Commands(**dict(synth.FULL_WAVENET_CONFIG)).to(dev)
