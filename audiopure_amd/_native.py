@@ -50,6 +50,9 @@ SIGNATURES = {
     "ap_ctx_get_schedule": (_i, [_vp, _i, C.POINTER(_f), _i]),
     "ap_profile_enable": (_i, [_vp, _i]),
     "ap_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ap_conv_profile_enable": (_i, [_i]),
+    "ap_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i]),
+    "ap_conv_profile_launch": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ap_workspace_bytes": (_sz, [_vp, _i, _i]),
     "ap_embed": (_i, [_vp, _f, _fp, _vp]),
     "ap_init_conv": (_i, [_vp, _fp, _fp, _i, _i, _vp]),

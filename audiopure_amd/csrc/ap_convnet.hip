@@ -107,6 +107,48 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
   }
 }
 
+// Cout <= 4 (the UNet's output convolution, unet.py:432-436: 128 -> 1 channels at 32 x 32): an M = 1 "GEMM" leaves 63 of the 64
+// rows of an MFMA tile empty (the generic kernel ran it at 0.8 TFLOP/s).  One thread per output pixel instead, the whole
+// filter in LDS ([k][m], k = ci kh kw + ky kw + kx as packed for the generic kernel), an fp32 fma chain in k order; reads are
+// coalesced along W and the taps re-read L1 / L2.  Same contract as conv2d_f32_kernel (groups = 1).
+template <int MO>
+__global__ __launch_bounds__(256) void conv2d_few_kernel(ConvArgs a) {
+  extern __shared__ float wsm[];
+  const int KK = a.kh * a.kw, Kg = a.Cin * KK, HoWo = a.Ho * a.Wo, N = a.B * HoWo, HW = a.H * a.W;
+  for (int i = threadIdx.x; i < Kg * MO; i += 256) wsm[i] = a.wT[i];
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int bb = n / HoWo, pp = n % HoWo;
+  const int iy0 = (pp / a.Wo) * a.stride - a.pad_h, ix0 = (pp % a.Wo) * a.stride - a.pad;
+  const float *xb = a.x + ((size_t)bb * a.x_cstride + a.x_coff) * HW;
+  float acc[MO];
+#pragma unroll
+  for (int m = 0; m < MO; m++) acc[m] = 0.f;
+  for (int ci = 0; ci < a.Cin; ci++) {
+    const float *xc = xb + (size_t)ci * HW;
+    const float *wk = wsm + (size_t)ci * KK * MO;
+    for (int ky = 0; ky < a.kh; ky++) {
+      const int iy = iy0 + ky * a.dil_h;
+      for (int kx = 0; kx < a.kw; kx++) {
+        const int ix = ix0 + kx * a.dil_w;
+        const float v = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? xc[iy * a.W + ix] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MO; m++) acc[m] = fmaf(wk[(ky * a.kw + kx) * MO + m], v, acc[m]);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MO; m++) {
+    const size_t off = ((size_t)bb * a.Cout + m) * HoWo + pp;
+    float v = acc[m];
+    if (a.bias) v += a.bias[m];
+    if (a.res) v += a.res[off];
+    if (a.relu) v = fmaxf(v, 0.f);
+    a.out[off] = v;
+  }
+}
+
 // 128 x 128 tile variant for wide layers (Cout/g >= 128: UNet, ResNeXt stages 2-3, VGG 128+): 4 waves x (64 x 64 =
 // 2 x 2 accumulators), so each staged element feeds 4x the MFMAs of the 64 x 64 kernel, and the im2col index (ci, r)
 // of every element a thread stages advances incrementally by the chunk size instead of being re-derived by division
@@ -740,9 +782,93 @@ extern "C" int ap_conv2d_pack(const float *w, const float *scale, float *wT, int
   return 0;
 }
 
+// ---- per-kernel measurement of the conv family (bench.py, BASELINE configs[4]): while enabled every ap_conv2d_fwd launch is
+// bracketed by a pair of HIP events on its launch stream and its algorithmic flops (2 N M K) are summed per kernel class.
+namespace {
+struct ConvProf {
+  bool on = false;
+  std::vector<hipEvent_t> ev;                 // (start, stop) pairs
+  std::vector<double> flop;                   // per recorded launch
+  std::vector<int> cls;                       // kernel class per recorded launch: 0 big2<128,128>, 1 big2<64,128>, 2 big2<128,64>,
+  size_t used = 0;                            //   3 split / fp16-split, 4 big (no fragment image), 5 generic
+  std::vector<int> shape;                     // 9 ints per recorded launch: B Cin H W Cout kh kw stride groups
+} g_cprof;
+int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin, int H,
+                    int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride, int x_coff,
+                    void *stream, int *cls);
+}  // namespace
+
+extern "C" int ap_conv_profile_enable(int enable) {
+  g_cprof.on = enable != 0;
+  g_cprof.used = 0;
+  g_cprof.flop.clear();
+  g_cprof.cls.clear();
+  g_cprof.shape.clear();
+  return 0;
+}
+
+// launch i of the recording (before ap_conv_profile_read resets it): its time, flops and [B Cin H W Cout kh kw stride groups class]
+extern "C" int ap_conv_profile_launch(int i, double *ms, double *flop, int *shape10) {
+  if (i < 0 || (size_t)i >= g_cprof.flop.size() || !ms || !flop || !shape10) return 1;
+  AP_HIP(hipEventSynchronize(g_cprof.ev[2 * i + 1]));
+  float t = 0.f;
+  AP_HIP(hipEventElapsedTime(&t, g_cprof.ev[2 * i], g_cprof.ev[2 * i + 1]));
+  *ms = t;
+  *flop = g_cprof.flop[i];
+  for (int k = 0; k < 9; k++) shape10[k] = g_cprof.shape[9 * (size_t)i + k];
+  shape10[9] = g_cprof.cls[i];
+  return 0;
+}
+
+extern "C" int ap_conv_profile_read(double *ms_by_class, double *flop_by_class, int64_t *launches_by_class, int n_classes) {
+  if (!ms_by_class || !flop_by_class || !launches_by_class || n_classes < 6) { set_error("ap_conv_profile_read: bad argument"); return -22; }
+  for (int c = 0; c < n_classes; c++) { ms_by_class[c] = 0; flop_by_class[c] = 0; launches_by_class[c] = 0; }
+  for (size_t i = 0; i < g_cprof.flop.size(); i++) {
+    AP_HIP(hipEventSynchronize(g_cprof.ev[2 * i + 1]));
+    float ms = 0.f;
+    AP_HIP(hipEventElapsedTime(&ms, g_cprof.ev[2 * i], g_cprof.ev[2 * i + 1]));
+    ms_by_class[g_cprof.cls[i]] += ms;
+    flop_by_class[g_cprof.cls[i]] += g_cprof.flop[i];
+    launches_by_class[g_cprof.cls[i]] += 1;
+  }
+  g_cprof.used = 0;
+  g_cprof.flop.clear();
+  g_cprof.cls.clear();
+  g_cprof.shape.clear();
+  return 0;
+}
+
 extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias, const float *res, float *out, int B,
                              int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
                              int x_cstride, int x_coff, void *stream) {
+  int cls = 5;
+  if (!g_cprof.on)
+    return conv2d_fwd_impl(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, &cls);
+  if (g_cprof.used + 2 > g_cprof.ev.size())
+    for (int i = 0; i < 2; i++) {
+      hipEvent_t e;
+      AP_HIP(hipEventCreate(&e));
+      g_cprof.ev.push_back(e);
+    }
+  AP_HIP(hipEventRecord(g_cprof.ev[g_cprof.used], (hipStream_t)stream));
+  const int rc = conv2d_fwd_impl(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, &cls);
+  AP_HIP(hipEventRecord(g_cprof.ev[g_cprof.used + 1], (hipStream_t)stream));
+  if (rc) return rc;
+  const bool one_d = (relu >> 9) & 1;
+  const int dil = (relu >> 16) ? (relu >> 16) : 1;
+  const int ph = one_d ? 0 : pad, dh = one_d ? 1 : dil;
+  const long long Ho = (H + 2 * ph - dh * (kh - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+  g_cprof.used += 2;
+  g_cprof.flop.push_back(2.0 * (double)B * Ho * Wo * Cout * (double)(Cin / groups) * kh * kw);
+  g_cprof.cls.push_back(cls);
+  for (int v : {B, Cin, H, W, Cout, kh, kw, stride, groups}) g_cprof.shape.push_back(v);
+  return 0;
+}
+
+namespace {
+int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin, int H,
+                    int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride, int x_coff,
+                    void *stream, int *cls) {
   if (!x || !wT || !out || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || stride < 1 || pad < 0 ||
       groups < 1 || Cin % groups || Cout % groups || x_cstride < x_coff + Cin) {
     set_error("ap_conv2d_fwd: bad argument");
@@ -776,40 +902,64 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
                           conv_split_floats(Cout, Cin / groups, kh, kw, groups);
       if (Mg < 128) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
+        *cls = 3;
         conv2d_split_kernel<64, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, hfrag);
       } else {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+        *cls = 3;
         conv2d_split_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, hfrag);
       }
     } else if (split) {                                         // fp32 results on the bf16 pipe (3-way split operands)
       const __bf16 *sfrag = reinterpret_cast<const __bf16 *>(afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups));
       if (Mg < 128) {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
+        *cls = 3;
         conv2d_split_kernel<64, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, sfrag);
       } else {
         dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+        *cls = 3;
         conv2d_split_kernel<128, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, sfrag);
       }
     } else if (Mg < 128) {                                             // 64 <= Cout/g < 128
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
+      *cls = 1;
       conv2d_f32_big2_kernel<64, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
     } else if (tiles128 >= g_conv_frag_min_tiles) {
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+      *cls = 0;
       conv2d_f32_big2_kernel<128, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
-    } else {                                                    // few tiles (low-resolution layers): 128 x 64
+    } else if (((N + 63) / 64) * ((Mg + 127) / 128) * (long long)groups >= 192) {   // few tiles (low-resolution layers): 128 x 64
       dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+      *cls = 2;
       conv2d_f32_big2_kernel<128, 64><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+    } else {                                                    // fewer still (4 x 4 maps, the embedding's linear layers): 64 x 64,
+      dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 63) / 64), (unsigned)groups);   // twice the workgroups for 256 CUs
+      *cls = 2;
+      conv2d_f32_big2_kernel<64, 64><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+    }
+  } else if (groups == 1 && Cout <= 4 && (size_t)Cin * kh * kw * Cout * sizeof(float) <= 48 * 1024) {
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    const size_t sh = (size_t)Cin * kh * kw * Cout * sizeof(float);
+    *cls = 5;
+    switch (Cout) {
+      case 1: conv2d_few_kernel<1><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
+      case 2: conv2d_few_kernel<2><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
+      case 3: conv2d_few_kernel<3><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
+      default: conv2d_few_kernel<4><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
     }
   } else if (Mg >= 128 && kh <= 3 && kw <= 3 && many) {
     dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
+    *cls = 4;
     conv2d_f32_big_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   } else {
     dim3 grid((unsigned)((N + CBN - 1) / CBN), (unsigned)((Mg + CBM - 1) / CBM), (unsigned)groups);
+    *cls = 5;
     conv2d_f32_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   }
   AP_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace
 
 extern "C" int ap_affine_nchw(const float *x, const float *scale, const float *shift, float *y, int B, int C, int HW,
                               int x_cstride, int x_coff, int relu, void *stream) {

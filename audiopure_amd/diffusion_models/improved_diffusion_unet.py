@@ -131,6 +131,20 @@ class UNetModel(nn.Module):
                 N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), cout, cin_g, kh, kw, 1, N.stream()), "ap_conv2d_pack")
                 packed[m] = (wT, m.bias.detach().float().contiguous() if m.bias is not None else None, cout, kh, kw,
                              (m.stride[0] if hasattr(m, "stride") else 1), (m.padding[0] if hasattr(m, "padding") else 0))
+        # every ResBlock projects the SAME embedding vector (unet.py:182, emb_layers = SiLU -> Linear): one GEMM over the
+        # concatenated rows of all those Linear layers replaces one 256-column launch per block (24 of them per evaluation,
+        # each latency-bound at 58 us); a block then takes its own rows out of the result
+        rbs = [m for m in self.modules() if isinstance(m, ResBlock)]
+        wcat = torch.cat([rb.emb_layers[1].weight.detach().float() for rb in rbs], 0).contiguous()
+        bcat = torch.cat([rb.emb_layers[1].bias.detach().float() for rb in rbs], 0).contiguous()
+        wT = torch.empty(lib.ap_conv2d_packed_elems(wcat.shape[0], wcat.shape[1], 1, 1, 1), device=dev, dtype=torch.float32)
+        N.check(lib.ap_conv2d_pack(N.ptr(wcat), None, N.ptr(wT), wcat.shape[0], wcat.shape[1], 1, 1, 1, N.stream()), "ap_conv2d_pack")
+        self._emb_cat = (wT, bcat, wcat.shape[0])
+        self._emb_rows, off = {}, 0
+        for rb in rbs:
+            n = rb.emb_layers[1].weight.shape[0]
+            self._emb_rows[rb] = (off, n)
+            off += n
         torch.cuda.synchronize(dev)
         self._packed, self._key = packed, key
         self._packed_t = {}                                # transposed images for the input gradient, built on first use
@@ -161,10 +175,12 @@ class UNetModel(nn.Module):
             self._tape.append(("gn", gn, x, ss, act, y))
         return y
 
-    def _resblock(self, rb, x, emb_silu):
+    def _resblock(self, rb, x, emb_proj):
         B, C_, H, W = x.shape
         h = self._conv(rb.in_layers[2], self._gn(rb.in_layers[0], x), B, C_, H, W)                 # unet.py:181
-        ss = self._conv(rb.emb_layers[1], emb_silu, B, emb_silu.shape[1], 1, 1, track=False).view(B, -1)   # :182 (SiLU applied once)
+        off, n = self._emb_rows[rb]                                                                 # :182: this block's rows of the
+        ss = torch.empty((B, n), device=x.device, dtype=torch.float32)                              # one projection of the step
+        N.check(N.lib().ap_copy_channels(N.ptr(emb_proj), N.ptr(ss), B, n, 1, emb_proj.shape[1], off, n, 0, N.stream()))
         h = self._gn(rb.out_layers[0], h, ss=ss)                                                   # :186-190 (+ SiLU)
         skip = x if isinstance(rb.skip_connection, nn.Identity) else self._conv(rb.skip_connection, x, B, C_, H, W)
         return self._conv(rb.out_layers[3], h, B, rb.out_channels, H, W, res=skip)                 # :194
@@ -178,11 +194,11 @@ class UNetModel(nn.Module):
             self._tape.append(("attn", qkv, att, ab.num_heads))
         return self._conv(ab.proj_out, att, B, C_, H, W, res=x)                                    # :234-235
 
-    def _run(self, seq, h, emb_silu):
+    def _run(self, seq, h, emb_proj):
         for layer in seq:
             B, C_, H, W = h.shape
             if isinstance(layer, ResBlock):
-                h = self._resblock(layer, h, emb_silu)
+                h = self._resblock(layer, h, emb_proj)
             elif isinstance(layer, AttentionBlock):
                 h = self._attention(layer, h)
             elif isinstance(layer, Downsample):
@@ -232,13 +248,17 @@ class UNetModel(nn.Module):
         e_s = torch.empty_like(e)
         N.check(lib.ap_silu(N.ptr(e), N.ptr(e_s), e.numel(), N.stream()))
         emb = self._conv(self.time_embed[2], e_s, B, e.shape[1], 1, 1, track=False).view(B, -1)    # unet.py:479
-        emb_silu = torch.empty_like(emb)                                   # every ResBlock starts emb_layers with SiLU
-        N.check(lib.ap_silu(N.ptr(emb), N.ptr(emb_silu), emb.numel(), N.stream()))
+        emb_s = torch.empty_like(emb)                                      # every ResBlock starts emb_layers with SiLU
+        N.check(lib.ap_silu(N.ptr(emb), N.ptr(emb_s), emb.numel(), N.stream()))
+        wT, bcat, total = self._emb_cat                                    # all blocks' emb_layers Linear in one GEMM: [B, total]
+        emb_proj = torch.empty((B, total), device=dev, dtype=torch.float32)
+        N.check(lib.ap_conv2d_fwd(N.ptr(emb_s), N.ptr(wT), N.ptr(bcat), None, N.ptr(emb_proj), B, emb.shape[1], 1, 1, total, 1, 1, 1,
+                                  0, 1, getattr(self, "_conv_flags", 0), emb.shape[1], 0, N.stream()), "ap_conv2d_fwd")
         hs, h = [], x
         for blk in self.input_blocks:                                       # :486-488
-            h = self._run(blk, h, emb_silu)
+            h = self._run(blk, h, emb_proj)
             hs.append(h)
-        h = self._run(self.middle_block, h, emb_silu)
+        h = self._run(self.middle_block, h, emb_proj)
         for blk in self.output_blocks:                                      # :490-492
             skip = hs.pop()
             Bc, C1, H, W = h.shape
@@ -248,7 +268,7 @@ class UNetModel(nn.Module):
             N.check(lib.ap_copy_channels(N.ptr(skip), N.ptr(cat), Bc, C2, H * W, C2, 0, C1 + C2, C1, N.stream()))
             if self._tape is not None:
                 self._tape.append(("cat", h, skip, cat))
-            h = self._run(blk, cat, emb_silu)
+            h = self._run(blk, cat, emb_proj)
         Bc, C_, H, W = h.shape
         return self._conv(self.out[2], self._gn(self.out[0], h), Bc, C_, H, W)                     # :494
 

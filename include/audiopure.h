@@ -123,6 +123,17 @@ int ap_ctx_get_schedule(ap_ctx *ctx, int which, float *out_host, int n);
 int ap_profile_enable(ap_ctx *ctx, int enable);
 int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches);
 
+/* The same hook for the conv-as-GEMM family (BASELINE configs[4]; replaces nothing in the reference -- it times the kernels
+ * that stand in for nn.Conv2d / nn.Conv1d / nn.Linear of improved_diffusion/unet.py:462-491 and models/resnext.py:67-142):
+ * while enabled every ap_conv2d_fwd launch is bracketed by HIP events on its stream.  ap_conv_profile_read sums kernel
+ * time, algorithmic flops (2 N M K) and launches per kernel class -- 0 conv2d_f32_big2<128,128>, 1 big2<64,128>,
+ * 2 big2<128,64>, 3 split-operand kernels, 4 conv2d_f32_big, 5 generic -- into caller arrays of n_classes >= 6, and resets. */
+int ap_conv_profile_enable(int enable);
+int ap_conv_profile_read(double *ms_by_class, double *flop_by_class, int64_t *launches_by_class, int n_classes);
+/* Launch i of the current recording (call before ap_conv_profile_read): time, flops, [B Cin H W Cout kh kw stride groups class];
+ * returns 1 past the last launch. */
+int ap_conv_profile_launch(int i, double *ms, double *flop, int *shape10);
+
 /* Workspace the eps/purify entry points need for a batch of B clips of L samples. */
 size_t ap_workspace_bytes(const ap_ctx *ctx, int B, int L);
 
