@@ -74,9 +74,9 @@ PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16",
                      "on the fp16 MFMA, fp32 accumulate"}
 
 
-PMC_FILES = {"f32": ["r2_pmc_traffic.json", "r1_pmc_traffic.json"], "f32s": ["r2_f32s_pmc_traffic.json", "r1_f32s_pmc_traffic.json"],
-             "f32h": ["r2_f32h_pmc_traffic.json", "r1_f32h_pmc_traffic.json"],
-             "bf16": ["r2_bf16_pmc_traffic.json", "r1_bf16_pmc_traffic.json"]}
+PMC_FILES = {"f32": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3_f32s_pmc_traffic.json", "r2_f32s_pmc_traffic.json"],
+             "f32h": ["r3_f32h_pmc_traffic.json", "r2_f32h_pmc_traffic.json"],
+             "bf16": ["r3_bf16_pmc_traffic.json", "r2_bf16_pmc_traffic.json"]}
 
 
 def pmc_traffic(B, precision="f32"):
@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + gather protocol; no kernels")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="clips per chain call (0 = the engine's default for the mode): the batch of a step is walked in chunks "
+                         "whose activations (3 x 65.5 MB per clip) stay resident in the 256 MB Infinity Cache")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -347,7 +350,8 @@ def main():
                 t=n, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1))
         system = AcousticSystem(classifier=m5, transform=None, defender=defender, defense_type="wave")
         eng = net.engine()
-        eng.max_chunk = B
+        eng.max_chunk = args.chunk if args.chunk > 0 else B
+        run_mode.chunk = min(eng.max_chunk, B)
 
         def step():
             lp = system(x0, True)                               # purify (n reverse steps) + classify, all in HIP
@@ -377,6 +381,10 @@ def main():
         return elapsed, tot_ms.value / max(launches.value, 1), int(launches.value)
 
     def roofline(precision, k_ms, launches):
+        Bl = getattr(run_mode, "chunk", B)                       # clips per residual-block launch
+        return roofline_b(precision, k_ms, launches, Bl)
+
+    def roofline_b(precision, k_ms, launches, B):
         achieved = FLOP_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e12
         traffic, traffic_source = pmc_traffic(B, precision)
         if precision == "f32":
@@ -406,7 +414,7 @@ def main():
             roof = {"bound": "hbm", "kernel": "resblock_bf16p_kernel (persistent, every dilation)", "achieved": round(gbs, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic,
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4)}
-        roof.update({"traffic_source": traffic_source, "launches": launches, "avg_launch_ms": round(k_ms, 4),
+        roof.update({"traffic_source": traffic_source, "launches": launches, "clips_per_launch": B, "avg_launch_ms": round(k_ms, 4),
                      "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,
                      "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
                      "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)})
