@@ -103,7 +103,13 @@ def text(name, dst):
 
 
 for n, d in (("bench.json", "r3_bench.json"), ("bench_torchrun_n1.json", "r3_bench_torchrun_n1.json"), ("kernel_stats.csv", "r3_kernel_stats.csv")):
-    if os.path.exists(os.path.join(src, n)):
+    if not os.path.exists(os.path.join(src, n)):
+        continue
+    if n.endswith(".json"):                          # the JSON line only (RCCL prints its version banner on stdout too)
+        lines = [l for l in open(os.path.join(src, n)) if l.lstrip().startswith("{")]
+        if lines:
+            open(os.path.join(P, d), "w").write(lines[-1])
+    else:
         shutil.copy(os.path.join(src, n), os.path.join(P, d))
 text("phase_trace.txt", "r3_bf16_phase_trace.txt")
 text("ablation.txt", "r3_bf16_ablation_persistent.txt")
