@@ -9,9 +9,17 @@
 //     768 KB instead of 1.5 MB per tile in GEMM1, 512 KB instead of 1 MB in GEMM2), every barrier has four participants,
 //     and no two waves of a SIMD compete for its issue port or its matrix pipe: the instruction stream of a wave IS the
 //     schedule of its SIMD, written out below (explicit order, pinned with sched_barrier).
-//   * the spare registers carry what the eight-wave kernel had to burst: the residual's h patch and the running skip rows are
-//     requested during the gate into registers that do not alias the accumulators, the next tile's first chunk and weight
-//     fragments go out before the last stores.
+//   * the spare registers carry what the eight-wave kernel had to burst: a fragment ring of eight k-steps (128 registers),
+//     the residual's h patch requested during the gate, the running skip rows into the registers the dead GEMM1 accumulators free.
+//
+// RESULT (profiles/r3_bf16w_one_wave_per_simd_experiment.txt): bit-identical to the product kernel and 20 % SLOWER
+// (6.1-6.4 ms against 5.2 per 256-clip launch).  A chunk of 96 MFMAs per wave takes 3.7 k cycles bare, 4.4 k with its 96 KB of weight
+// fragments, 5.2 k when it also re-requests 48 KB of cache-resident X rows and 6-7 k when those rows are new -- with a fragment ring of
+// 3, 4, 6 or 8 k-steps, with 5 or 11 k-steps between an X request and its pack, with the requests in bursts or one per MFMA gap:
+// the time the CU's one address pipeline (64 B/clk, all waves) needs for a wave's memory instructions ADDS to its MFMA time,
+// because the wave that waits at that pipeline's door is the only one that could issue its SIMD's MFMAs.  Two waves per SIMD hide
+// part of it (the partner issues meanwhile); separate loader waves would hide all of it, and the register file has no room for
+// them (the accumulators of the 512 x 128 tile are half of it, the fragment rings want registers, not LDS).  Tools library only.
 //
 // Layouts (unchanged): X image [column][k] bf16 with 208-B rows and the 32-byte parity swizzle, g image [column][channel]
 // with 528-B rows, wave-private 32 x 32 fp32 output patch.  Weight images: wave v of this kernel reads the fragments that
@@ -143,7 +151,8 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
   // Two register sets: chunk c lives in set c & 1 from its request (during chunk c - 3) to its pack (during chunk c - 1) -- eleven
   // k-steps of sixteen MFMAs between a request and its first use, where one set allowed five: with ONE wave per SIMD a k-step
   // takes half the time it took the eight-wave kernels, and an HBM miss does not.
-  float xrA[3][4][4], xrB[3][4][4];                              // [tap][channel of the quad][sample]
+  constexpr bool TWO = false;                                    // two staging register sets (chunk c + 3 requested during chunk c) or one (c + 2)
+  float xrA[3][4][4], xrB[3][4][4];                              // [tap][channel of the quad][sample]; xrB unused unless TWO
   unsigned xvoff[3], xkeep[3];
   auto x_geom = [&](int t0) {
 #pragma unroll
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
   };
   auto issue_x_tap = [&](const __amdgpu_buffer_rsrc_t &rs, int ch, auto set_tag, auto t_tag) {
     constexpr int T = decltype(t_tag)::value;
-    auto &xr = decltype(set_tag)::value ? xrB : xrA;
+    auto &xr = (TWO && decltype(set_tag)::value) ? xrB : xrA;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
       const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvoff[T], (ch * KC_ + e) * L * 4, 0));
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
   };
   auto issue_x1 = [&](const __amdgpu_buffer_rsrc_t &rs, int ch, auto set_tag, auto t_tag, auto e_tag) {
     constexpr int T = decltype(t_tag)::value, e = decltype(e_tag)::value;
-    auto &xr = decltype(set_tag)::value ? xrB : xrA;
+    auto &xr = (TWO && decltype(set_tag)::value) ? xrB : xrA;
     const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvoff[T], (ch * KC_ + e) * L * 4, 0));
 #pragma unroll
     for (int i = 0; i < 4; i++) xr[T][e][i] = v[i];
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
   // one twelfth of a chunk's staging: sample i of tap T -- 4 adds, 2 cvt_pk, 2 and, 1 ds_write_b64
   auto pack_piece = [&](unsigned char *dst, auto set_tag, auto t_tag, auto i_tag) {
     constexpr int T = decltype(t_tag)::value, i = decltype(i_tag)::value;
-    auto &xr = decltype(set_tag)::value ? xrB : xrA;
+    auto &xr = (TWO && decltype(set_tag)::value) ? xrB : xrA;
     unsigned pk[2];
 #pragma unroll
     for (int e2 = 0; e2 < 2; e2++)
@@ -226,17 +235,17 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
   tile_bt(t_first, b_cur, t0_cur);
   __amdgpu_buffer_rsrc_t hrs = clip_rsrc(hin, b_cur);
   x_geom(t0_cur);
-  constexpr int RING = 4;                                        // fragment ring depth in k-steps (4 fragments each)
+  constexpr int RING = 8;                                        // fragment ring depth in k-steps (4 fragments each)
   bf16x8 w[RING][4];
   auto tile_head = [&]() {
 #pragma unroll
     for (int ks = 0; ks < RING; ks++)
 #pragma unroll
       for (int f = 0; f < 4; f++) w[ks][f] = ld_w1(ks, f);
-    issue_x(hrs, 1, I1{});                                       // chunk 1: packed in chunk 0 (a short lead, once per tile)
+    if constexpr (TWO) issue_x(hrs, 1, I1{});                    // chunk 1: packed in chunk 0 (a short lead, once per tile)
     pack_ptv(0);
     pack_tap(lds, I0{}, I0{}); pack_tap(lds, I0{}, I1{}); pack_tap(lds, I0{}, I2{});
-    issue_x(hrs, 2, I0{});                                       // chunk 2: packed in chunk 1
+    issue_x(hrs, TWO ? 2 : 1, I0{});                             // chunk 2 (1): packed in chunk 1 (0)
   };
   issue_x(hrs, 0, I0{});
   __syncthreads();                                               // part_t, biases visible
@@ -293,10 +302,10 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
     // MFMAs (column tile 3) by those of the k-step RING on.  Chunk c packs chunk c + 1 (tap T in k-step T, one sample per
     // column tile) out of register set (c + 1) & 1 and requests chunk c + 3 into the same set, tap T one k-step behind its
     // pack and behind that k-step's fragment requests.
-    auto chunk = [&](const unsigned char *xbe, const unsigned char *xbo, int ch, unsigned char *pdst, auto set_tag, auto kind_tag) {
+    auto chunk = [&](const unsigned char *xbe, const unsigned char *xbo, int ch, unsigned char *pdst, auto set_tag, auto kind_tag, auto ph_tag) {
       constexpr int KIND = decltype(kind_tag)::value;            // 0: pack + request, 1: pack only, 2: neither (last chunk)
       constexpr bool LAST = KIND == 2, WITH_X = KIND == 0;
-      constexpr int PH = (1 - decltype(set_tag)::value) * (6 % RING);   // ring slot of this chunk's k-step 0: set = (ch + 1) & 1, so odd chunks start 6 % RING on
+      constexpr int PH = decltype(ph_tag)::value;                // ring slot of this chunk's k-step 0 = (6 ch) mod RING
       bf16x8 bv[4];
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) rdb(bv[ct], xbe, xbo, ct, 0);
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
             }
             if constexpr (WITH_X && !(DBG & 2)) {
               if (f == 2 && ks >= 1 && ks <= 3) {               // one request per MFMA gap, never a burst: a wave that waits at
-                const int chx = min(ch + 3, NCH - 1);            // the memory pipe's door issues no MFMA either
+                const int chx = min(ch + (TWO ? 3 : 2), NCH - 1); // the memory pipe's door issues no MFMA either
                 if (ks == 1) { if (ct == 0) issue_x1(hrs, chx, set_tag, I0{}, I0{}); if (ct == 1) issue_x1(hrs, chx, set_tag, I0{}, I1{});
                                if (ct == 2) issue_x1(hrs, chx, set_tag, I0{}, I2{}); if (ct == 3) issue_x1(hrs, chx, set_tag, I0{}, I3{}); }
                 if (ks == 2) { if (ct == 0) issue_x1(hrs, chx, set_tag, I1{}, I0{}); if (ct == 1) issue_x1(hrs, chx, set_tag, I1{}, I1{});
@@ -342,22 +351,24 @@ __global__ __launch_bounds__(256, 1) void resblock_bf16w_kernel(
     };
     auto xb = [&](int ch) { return lds + (ch & 1) * XBYTES + rdoff + rdsw; };
     static_assert(NCH == 8, "chunk schedule below is written for eight chunks");
-#pragma unroll 1
-    for (int ch = 0; ch < 6; ch += 2) {                         // chunks 0..5: pack c + 1, request c + 3 (chunk 5 re-requests 7: dropped)
-      chunk(xb(ch), xb(ch) - 2 * rdsw, ch, lds + XBYTES, I1{}, I0{});
-      mark(3 + 2 * ch);
-      __syncthreads();
-      mark(4 + 2 * ch);
-      chunk(xb(ch + 1), xb(ch + 1) - 2 * rdsw, ch + 1, lds, I0{}, I0{});
-      mark(5 + 2 * ch);
-      __syncthreads();
-      mark(6 + 2 * ch);
-    }
-    chunk(xb(6), xb(6) - 2 * rdsw, 6, lds + XBYTES, I1{}, I1{});  // packs 7
-    mark(15);
-    __syncthreads();
-    mark(16);
-    chunk(xb(7), xb(7) - 2 * rdsw, 7, nullptr, I0{}, I2{});
+    using P0 = std::integral_constant<int, 0>;
+    using P6 = std::integral_constant<int, 6 % RING>;
+    using P4 = std::integral_constant<int, 12 % RING>;
+    using P2 = std::integral_constant<int, 18 % RING>;
+#define AP_W_CHUNK(CH, PDST, SET, KIND, PH, M)                   \
+    chunk(xb(CH), xb(CH) - 2 * rdsw, CH, PDST, SET{}, KIND{}, PH{}); \
+    mark(M);                                                     \
+    __syncthreads();                                             \
+    mark(M + 1);
+    AP_W_CHUNK(0, lds + XBYTES, I1, I0, P0, 3)
+    AP_W_CHUNK(1, lds, I0, I0, P6, 5)
+    AP_W_CHUNK(2, lds + XBYTES, I1, I0, P4, 7)
+    AP_W_CHUNK(3, lds, I0, I0, P2, 9)
+    AP_W_CHUNK(4, lds + XBYTES, I1, I0, P0, 11)
+    AP_W_CHUNK(5, lds, I0, I0, P6, 13)
+    AP_W_CHUNK(6, lds + XBYTES, I1, I1, P4, 15)
+#undef AP_W_CHUNK
+    chunk(xb(7), xb(7) - 2 * rdsw, 7, nullptr, I0{}, I2{}, P2{});
     mark(17);
 
     // ================================================ gate ==========================================================
