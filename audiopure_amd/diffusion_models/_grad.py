@@ -93,6 +93,17 @@ class EpsGrad:
         N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(packed), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, 1, L, Cout, 1, kw, 1,
                                   pad, 1, fl, Cin, 0, N.stream()), "ap_conv2d_fwd")
 
+    def saved_bytes(self, x: torch.Tensor, acts: bool = True) -> int:
+        """Bytes ``forward_save(x, ., acts)`` keeps, computed without allocating: NL + 1 layer inputs [B][C][L], the skip sum,
+        the FiLM vectors and -- ``acts`` in fp32 arithmetic -- NL pre-gate tensors [B][2C][L]."""
+        eng = self._prepare()
+        B, _, L = x.shape
+        C_, S_, NL = self.C, self.S, self.NL
+        n = (NL + 1) * B * C_ * L + B * S_ * L + NL * C_ + eng.cfg.embed_dim_out
+        if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256):
+            n += NL * B * 2 * C_ * L
+        return 4 * n
+
     def eps_only(self, x: torch.Tensor, step: float):
         """The plain fused forward (``ap_eps_fwd``): what the chain's forward pass calls -- nothing is kept."""
         with torch.no_grad():
@@ -182,7 +193,18 @@ def _axpby(x, y, a, b):
     return out
 
 
-SAVE_BUDGET_BYTES = 96 << 30      # per chain: what the links keep for the backward pass while it fits (288 GB of HBM)
+SAVE_BUDGET_BYTES = 96 << 30      # ceiling per chain of what the links keep for the backward pass (288 GB of HBM)
+SAVE_FREE_FRACTION = 0.6          # ... and never more than this share of the device memory that is free when the chain starts
+
+
+def _chain_budget(device) -> int:
+    """What one chain may keep: the ceiling, capped by a share of the memory that is actually free (several chains -- EOT
+    samples, sample_step > 1 -- start one after the other, each seeing what the earlier ones hold)."""
+    try:
+        free, _ = torch.cuda.mem_get_info(device)
+    except (RuntimeError, AssertionError):
+        return SAVE_BUDGET_BYTES
+    return int(min(SAVE_BUDGET_BYTES, SAVE_FREE_FRACTION * free))
 
 
 def _saved_bytes(saved) -> int:
@@ -219,20 +241,26 @@ class _ChainFn(torch.autograd.Function):
                 cur = _axpby(cur, zs[0], qa, qs)
             elif qa != 1.0:
                 cur = _axpby(cur, None, qa, 0.0)
-            full = lean = None                                   # bytes a link keeps with / without the pre-gate activations
+            budget = _chain_budget(cur.device)
+            sizes = getattr(grad, "saved_bytes", None)           # analytic sizes where the gradient object knows them: nothing is
+            full = sizes(cur, True) if sizes else None           # allocated to find out that it does not fit
+            lean = sizes(cur, False) if sizes else None
             for (t, ca, cb, cs, draw) in steps:
                 xs.append(cur)
-                if full is None or held + full <= SAVE_BUDGET_BYTES:
+                if full is None:                                 # (a gradient object without sizes: measure its first link)
                     eps, saved = grad.forward_save(cur, t)
-                    if full is None:
-                        full = _saved_bytes(saved)
-                        lean = _saved_bytes(saved[:3]) if isinstance(saved, tuple) and len(saved) == 4 else full
-                        if full > SAVE_BUDGET_BYTES:
-                            saved = None if lean > SAVE_BUDGET_BYTES else saved[:3] + (None,)
+                    full = _saved_bytes(saved)
+                    lean = _saved_bytes(saved[:3]) if isinstance(saved, tuple) and len(saved) == 4 else full
+                    if full > budget:
+                        saved = None if lean > budget else saved[:3] + (None,)
                     if saved is not None:
                         held += _saved_bytes(saved)
                     saves.append(saved)
-                elif lean < full and held + lean <= SAVE_BUDGET_BYTES:
+                elif held + full <= budget:
+                    eps, saved = grad.forward_save(cur, t)
+                    held += full
+                    saves.append(saved)
+                elif lean < full and held + lean <= budget:
                     eps, saved = grad.forward_save(cur, t, acts=False)    # layer inputs only: the backward recomputes the dilated conv
                     held += lean
                     saves.append(saved)

@@ -70,8 +70,13 @@ class RobustCertificate():
         return out
 
     @torch.no_grad()
-    @N.on_device
     def smooth_predict(self, x: torch.Tensor, num_sampling: int = 100, sigma=0.25, batch_size=64):
+        """(RobustCertificate is no nn.Module and accepts CPU input, so the classifier's device is made current here: streams,
+        allocations and every native launch of the body bind to it.)"""
+        with torch.cuda.device(next(self.classifier.parameters()).device):
+            return self._smooth_predict(x, num_sampling, sigma, batch_size)
+
+    def _smooth_predict(self, x: torch.Tensor, num_sampling: int = 100, sigma=0.25, batch_size=64):
         assert (x.shape[0] == 1)                                             # :36
         dev = next(self.classifier.parameters()).device
         x = x.to(dev).float().reshape(1, 1, -1)
@@ -86,7 +91,7 @@ class RobustCertificate():
                 x_in = self.transform(x_in)
             scores = self.classifier(x_in).float().contiguous()
             assert scores.shape[1] == self.num_classes
-            N.check(N.lib().ap_argmax_hist(N.ptr(scores), counts.data_ptr(), nb, self.num_classes, N.stream()),
+            N.check(N.lib().ap_argmax_hist(N.ptr(scores), counts.data_ptr(), nb, self.num_classes, N.stream()),   # (int64 tensor, allocated on the device made current above)
                     "ap_argmax_hist")
             done += nb
         counts = counts.cpu()
@@ -96,7 +101,6 @@ class RobustCertificate():
         return counts[:-1]
 
     @torch.no_grad()
-    @N.on_device
     def certify(self, x: torch.Tensor, y: torch.Tensor, sigma: float = 0.25, n_0: int = 100, n: int = 100000,
                 alpha: float = 0.001, batch_size: int = 64):                 # :67-97
         y_pred, radius = -torch.ones_like(y), torch.zeros_like(y, dtype=torch.float32)
