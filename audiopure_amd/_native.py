@@ -50,6 +50,7 @@ SIGNATURES = {
     "ap_ctx_get_schedule": (_i, [_vp, _i, C.POINTER(_f), _i]),
     "ap_profile_enable": (_i, [_vp, _i]),
     "ap_profile_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ap_conv2d_set_workspace": (_i, [_vp, _sz]),
     "ap_conv_profile_enable": (_i, [_i]),
     "ap_conv_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), _i]),
     "ap_conv_profile_launch": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
@@ -184,6 +185,22 @@ def on_device(fn):
         with torch.cuda.device(dev):
             return fn(self, *args, **kw)
     return wrapper
+
+
+_CONV_WS = {}                                    # device index -> the tensor the library's split-K path writes its partial sums to
+CONV_WS_BYTES = 64 << 20
+
+
+def use_conv_workspace(device) -> None:
+    """Hand the library this device's split-K workspace (``ap_conv2d_set_workspace``; allocated once per device by torch's
+    caching allocator and kept alive here -- the library itself allocates nothing).  Called at the entry of every native
+    conv-net forward, so the pointer the library holds always belongs to the device the launches go to."""
+    import torch
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _CONV_WS.get(idx)
+    if ws is None:
+        ws = _CONV_WS[idx] = torch.empty(CONV_WS_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+    check(lib().ap_conv2d_set_workspace(ws.data_ptr(), CONV_WS_BYTES), "ap_conv2d_set_workspace")
 
 
 def stream() -> int:

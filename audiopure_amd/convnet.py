@@ -440,6 +440,7 @@ class NativeConvNet(nn.Module):
         dev = x.device
         if self._dev_weights is None or self._dev != dev:
             self._prepare(dev)
+        N.use_conv_workspace(dev)
         lib, W, B, st_ = N.lib(), self._dev_weights, x.shape[0], N.stream()
         bufs = {self.plan.input.buf: x.detach().float().contiguous()}
 

@@ -19,6 +19,8 @@ struct ConvArgs {
   int pad_h, dil_h, dil_w;   // pad applies to W; pad_h / dil_h to H (equal to pad / dil_w except in 1-D mode: 0 / 1)
   int x_cstride;     // channels of the tensor x lives in (>= Cin when x is a channel slice of a wider tensor)
   int x_coff;        // first channel of the slice
+  int splits;        // > 1: split-K (groups == 1): blockIdx.z = slice of the chunk range, raw partial sums go to `part`
+  float *part;       // [splits][B][Cout][Ho][Wo]
 };
 
 __device__ __forceinline__ int crowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -272,8 +274,13 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
 //  * the weights are pre-packed in the MFMA A-operand layout ([group][32-row tile][k'/8][lane][4]) and go L2 ->
 //    registers as dwordx4, one chunk ahead: no LDS, no stores, no bank traffic for them (LDS holds only the 16 KB
 //    double-buffered im2col tile, so more workgroups fit a CU).
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag) {
+// BUF (round 3; tensors and weight image below 2 GB each, which the host checks): every global access is a buffer load with a
+// 32-bit VGPR offset computed once per chunk and the row / fragment step in the SCALAR offset, padding taps read through an
+// out-of-range offset (returns 0) -- the 64-bit per-load address arithmetic and the selects of the pointer form were 2.9 VALU
+// + 2 SALU instructions per MFMA, and the chip held 1.95 GHz under them against 2.38 under the fused block.
+template <int BM, int BN, bool BUF = true>
+__global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag, unsigned x_bytes,
+                                                                 unsigned a_bytes) {
   // 2 x 2 waves, each (BM/2 rows x BN/2 columns): BM x BN = 128 x 128, 128 x 64 (layers with few tiles), 64 x 128
   // (64 <= Cout/g < 128: ResNeXt's grouped 3x3)
   constexpr int BK = 16, NX = BM / 64, NY = BN / 64, EPT = BK * BN / 256, KSTEP = 256 / BN;
@@ -283,7 +290,8 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   const int j = lane & 31, hh = lane >> 5;
   const int Mg = a.Cout / a.groups, Cg = a.Cin / a.groups, KK = a.kh * a.kw, Kg = Cg * KK;
   const int HoWo = a.Ho * a.Wo, N = a.B * HoWo;
-  const int g = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int g = a.splits > 1 ? 0 : blockIdx.z, zs = a.splits > 1 ? blockIdx.z : 0;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int nl = tid & (BN - 1), kq = tid / BN;        // element i of a thread: chunk row kq + KSTEP i, column nl
   const int n = n0 + nl;
   const bool nvalid = n < N;
@@ -300,23 +308,50 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   }
   const int nchunk = KK * CPT;
   float br[EPT];
+  auto uni_rsrc = [&](const void *base, unsigned bytes) {
+    const uint64_t hb = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t xrs = uni_rsrc(a.x, BUF ? x_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ars = uni_rsrc(afrag, BUF ? a_bytes : 0u);
+  const unsigned xb_off = (unsigned)(((size_t)bb * a.x_cstride + a.x_coff + (size_t)g * Cg + kq) * HW);   // elements (BUF: < 2^29)
+  unsigned af_off[NX];
+#pragma unroll
+  for (int x_ = 0; x_ < NX; x_++) {
+    const int mt = min((m0 >> 5) + NX * wm + x_, MT - 1);
+    af_off[x_] = (unsigned)((((size_t)g * MT + mt) * KQ * 64 + lane) * 16);
+  }
   auto load_b = [&](int c) {                                   // chunk c = (tap r, channels c0 .. c0+15)
     const int r = c / CPT, c0 = (c - r * CPT) * BK;
     const int ky = r / a.kw, kx = r - ky * a.kw;
     const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
     const bool ok = nvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
+    if constexpr (BUF) {
+      const unsigned voff = ok ? (xb_off + (unsigned)(c0 * HW + iy * a.W + ix)) * 4u : 0x80000000u;   // out of range -> 0
 #pragma unroll
-    for (int i = 0; i < EPT; i++) {
-      const float v = p[(size_t)(KSTEP * i) * HW];
-      br[i] = ok ? v : 0.f;
+      for (int i = 0; i < EPT; i++)
+        br[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, KSTEP * i * HW * 4, 0));
+    } else {
+      const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
+#pragma unroll
+      for (int i = 0; i < EPT; i++) {
+        const float v = p[(size_t)(KSTEP * i) * HW];
+        br[i] = ok ? v : 0.f;
+      }
     }
   };
   auto load_a = [&](f32x4(&aa)[NX][2], int c) {
 #pragma unroll
     for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
-      for (int q = 0; q < 2; q++) aa[x_][q] = af[x_][(size_t)(2 * c + q) * 64];
+      for (int q = 0; q < 2; q++) {
+        if constexpr (BUF)
+          aa[x_][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, af_off[x_], (2 * c + q) * 1024, 0));
+        else
+          aa[x_][q] = af[x_][(size_t)(2 * c + q) * 64];
+      }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
@@ -343,18 +378,21 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
     }
   };
 
+  // split-K (low-resolution layers, too few output tiles for 256 CUs): this workgroup sums chunks [cb, ce) only
+  const int cb = a.splits > 1 ? (int)((long long)nchunk * zs / a.splits) : 0;
+  const int ce = a.splits > 1 ? (int)((long long)nchunk * (zs + 1) / a.splits) : nchunk;
   f32x4 a0[NX][2], a1[NX][2];
-  load_a(a0, 0);
-  load_b(0);
+  load_a(a0, cb);
+  load_b(cb);
   store_b(0);
   __syncthreads();
 #pragma unroll 1
-  for (int c = 0; c < nchunk; c++) {
-    const int cn = c + 1 < nchunk ? c + 1 : c;                  // the last trip re-fetches its own chunk (unused)
+  for (int c = cb; c < ce; c++) {
+    const int cn = c + 1 < ce ? c + 1 : c;                      // the last trip re-fetches its own chunk (unused)
     load_b(cn);
     load_a(a1, cn);
-    compute(a0, c & 1);
-    store_b((c + 1) & 1);
+    compute(a0, (c - cb) & 1);
+    store_b((c - cb + 1) & 1);
 #pragma unroll
     for (int x_ = 0; x_ < NX; x_++)
 #pragma unroll
@@ -375,13 +413,36 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
             const int co = g * Mg + m;
             const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
             float v = acc[x_][y_][r];
-            if (a.bias) v += a.bias[co];
-            if (a.res) v += a.res[off];
-            if (a.relu) v = fmaxf(v, 0.f);
-            a.out[off] = v;
+            if (a.splits > 1) {                                 // raw partial sum; conv_splitk_reduce_kernel adds bias / residual / ReLU
+              a.part[(size_t)zs * ((size_t)a.B * a.Cout * HoWo) + off] = v;
+            } else {
+              if (a.bias) v += a.bias[co];
+              if (a.res) v += a.res[off];
+              if (a.relu) v = fmaxf(v, 0.f);
+              a.out[off] = v;
+            }
           }
         }
     }
+  }
+}
+
+// out = [ReLU](sum over the K slices in slice order (deterministic) + bias + residual); four consecutive outputs per thread
+__global__ void conv_splitk_reduce_kernel(ConvArgs a, size_t total) {
+  const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= total) return;
+  const int HoWo = a.Ho * a.Wo;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nv = (int)(total - i4 < 4 ? total - i4 : 4);
+  for (int z = 0; z < a.splits; z++)
+    for (int e = 0; e < nv; e++) v[e] += a.part[(size_t)z * total + i4 + e];
+  for (int e = 0; e < nv; e++) {
+    const size_t off = i4 + e;
+    float r = v[e];
+    if (a.bias) r += a.bias[(off / HoWo) % a.Cout];
+    if (a.res) r += a.res[off];
+    if (a.relu) r = fmaxf(r, 0.f);
+    a.out[off] = r;
   }
 }
 
@@ -798,6 +859,15 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
                     void *stream, int *cls);
 }  // namespace
 
+// Split-K partial sums live in a caller-owned device buffer (no allocation inside the library): without one, or with one
+// that is too small for a layer, that layer runs un-split.
+namespace { float *g_conv_ws = nullptr; size_t g_conv_ws_bytes = 0; }
+extern "C" int ap_conv2d_set_workspace(float *ws, size_t bytes) {
+  g_conv_ws = ws;
+  g_conv_ws_bytes = ws ? bytes : 0;
+  return 0;
+}
+
 extern "C" int ap_conv_profile_enable(int enable) {
   g_cprof.on = enable != 0;
   g_cprof.used = 0;
@@ -883,6 +953,7 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
   const int dil = (relu >> 16) ? (relu >> 16) : 1;
   relu &= 1;
   a.groups = groups; a.relu = relu; a.x_cstride = x_cstride; a.x_coff = x_coff;
+  a.splits = 1; a.part = nullptr;
   a.dil_w = dil;
   a.dil_h = one_d ? 1 : dil;
   a.pad_h = one_d ? 0 : pad;
@@ -897,6 +968,11 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
   if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
     const size_t n1 = (size_t)Cout * (Cin / groups) * kh * kw;
     const float *afrag = wT + ((n1 + 3) & ~(size_t)3);
+    // buffer-load form of the fp32 kernel: the activations' slab and the fragment image each below 2 GB (32-bit offsets,
+    // bit 31 marks the padding taps); larger tensors keep the pointer form
+    const size_t xbytes = (size_t)B * x_cstride * H * W * sizeof(float);
+    const size_t abytes = conv_frag_elems(Cout, Cin / groups, kh, kw, groups) * sizeof(float);
+    const bool buf = xbytes < ((size_t)1 << 31) && abytes < ((size_t)1 << 31);
     if (splith) {                                               // two fp16 parts per operand, three partial products
       const void *hfrag = afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups) +
                           conv_split_floats(Cout, Cin / groups, kh, kw, groups);
@@ -923,19 +999,45 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     } else if (Mg < 128) {                                             // 64 <= Cout/g < 128
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
       *cls = 1;
-      conv2d_f32_big2_kernel<64, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+      if (buf) conv2d_f32_big2_kernel<64, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      else conv2d_f32_big2_kernel<64, 128, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
     } else if (tiles128 >= g_conv_frag_min_tiles) {
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
       *cls = 0;
-      conv2d_f32_big2_kernel<128, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+      if (buf) conv2d_f32_big2_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      else conv2d_f32_big2_kernel<128, 128, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
+    } else if (buf && groups == 1 && !split && !splith && tiles128 * 2 < 384 && kh * kw * (Cin / 16) >= 32 && g_conv_ws &&
+               2 * (size_t)B * Cout * a.Ho * a.Wo * sizeof(float) <= g_conv_ws_bytes) {
+      // too few output tiles for 256 CUs and a long K (the 4 x 4 and 8 x 8 maps of the UNet: K = 2 304 .. 4 608): split-K over
+      // blockIdx.z, partial sums to the caller's workspace, slices summed in order by a second small kernel (deterministic)
+      const long long t64 = ((N + 63) / 64) * ((Mg + 63) / 64), t128x64 = ((N + 63) / 64) * ((Mg + 127) / 128);
+      const bool small = t128x64 < 192;
+      const long long tiles = small ? t64 : t128x64;
+      int S = 2;
+      while (S < 8 && tiles * S < 768 && kh * kw * (Cin / 16) / (2 * S) >= 16 &&
+             (size_t)(2 * S) * B * Cout * a.Ho * a.Wo * sizeof(float) <= g_conv_ws_bytes) S *= 2;
+      a.splits = S;
+      a.part = g_conv_ws;
+      *cls = 2;
+      if (small) {
+        dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 63) / 64), (unsigned)S);
+        conv2d_f32_big2_kernel<64, 64, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      } else {
+        dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 127) / 128), (unsigned)S);
+        conv2d_f32_big2_kernel<128, 64, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      }
+      const size_t total = (size_t)B * Cout * a.Ho * a.Wo;
+      conv_splitk_reduce_kernel<<<(unsigned)((total / 4 + 255) / 256 + 1), 256, 0, (hipStream_t)stream>>>(a, total);
     } else if (((N + 63) / 64) * ((Mg + 127) / 128) * (long long)groups >= 192) {   // few tiles (low-resolution layers): 128 x 64
       dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 127) / 128), (unsigned)groups);
       *cls = 2;
-      conv2d_f32_big2_kernel<128, 64><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+      if (buf) conv2d_f32_big2_kernel<128, 64, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      else conv2d_f32_big2_kernel<128, 64, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
     } else {                                                    // fewer still (4 x 4 maps, the embedding's linear layers): 64 x 64,
       dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 63) / 64), (unsigned)groups);   // twice the workgroups for 256 CUs
       *cls = 2;
-      conv2d_f32_big2_kernel<64, 64><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag);
+      if (buf) conv2d_f32_big2_kernel<64, 64, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      else conv2d_f32_big2_kernel<64, 64, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
     }
   } else if (groups == 1 && Cout <= 4 && (size_t)Cin * kh * kw * Cout * sizeof(float) <= 48 * 1024) {
     const unsigned grid = (unsigned)((N + 255) / 256);

@@ -235,6 +235,7 @@ class UNetModel(nn.Module):
     def _forward(self, x, timesteps):
         self._prepare()
         lib = N.lib()
+        N.use_conv_workspace(x.device)                                      # split-K partial sums of the 4 x 4 / 8 x 8 maps
         x = x.detach().float().contiguous()
         B, dev = x.shape[0], x.device
         if self._tape is not None:

@@ -128,6 +128,10 @@ int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches);
  * while enabled every ap_conv2d_fwd launch is bracketed by HIP events on its stream.  ap_conv_profile_read sums kernel
  * time, algorithmic flops (2 N M K) and launches per kernel class -- 0 conv2d_f32_big2<128,128>, 1 big2<64,128>,
  * 2 big2<128,64>, 3 split-operand kernels, 4 conv2d_f32_big, 5 generic -- into caller arrays of n_classes >= 6, and resets. */
+/* Caller-owned device buffer for the split-K partial sums of low-resolution conv layers (K sliced over workgroups when a layer
+ * has too few output tiles for the chip; slices are summed in order by a second kernel: deterministic).  NULL / 0 disables
+ * split-K; a layer whose partial sums do not fit runs un-split.  The library allocates nothing itself. */
+int ap_conv2d_set_workspace(float *ws, size_t bytes);
 int ap_conv_profile_enable(int enable);
 int ap_conv_profile_read(double *ms_by_class, double *flop_by_class, int64_t *launches_by_class, int n_classes);
 /* Launch i of the current recording (call before ap_conv_profile_read): time, flops, [B Cin H W Cout kh kw stride groups class];
