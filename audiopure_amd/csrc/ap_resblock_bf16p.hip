@@ -475,6 +475,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     auto mf = [&](const bf16x8 &a, const bf16x8 &bq, int rt, int ct) {
       if constexpr (DBG & 8) {
         asm volatile("" ::"v"(a), "v"(bq));
+      } else if constexpr (DBG & 0x100000) {                   // timing only: the same FLOPs as two v_mfma_f32_16x16x32_bf16 (results wrong)
+        f32x4 lo = __builtin_shufflevector(acc[rt][ct], acc[rt][ct], 0, 1, 2, 3);
+        f32x4 hi = __builtin_shufflevector(acc[rt][ct], acc[rt][ct], 4, 5, 6, 7);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq, hi, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { acc[rt][ct][i] = lo[i]; acc[rt][ct][4 + i] = hi[i]; }
       } else {
         acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq, acc[rt][ct], 0, 0, 0);
       }
@@ -703,7 +710,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll
         for (int ct = 0; ct < 4; ct++) {
           if constexpr (DBG & 64) asm volatile("" ::"v"(a), "v"(use[ct]));
-          else ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, use[ct], ac[ct], 0, 0, 0);
+          else if constexpr (DBG & 0x100000) {
+            f32x4 lo = __builtin_shufflevector(ac[ct], ac[ct], 0, 1, 2, 3), hi = __builtin_shufflevector(ac[ct], ac[ct], 4, 5, 6, 7);
+            lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, use[ct], lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, use[ct], hi, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ac[ct][i] = lo[i]; ac[ct][4 + i] = hi[i]; }
+          } else ac[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, use[ct], ac[ct], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -857,6 +870,8 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   } else if (ws > 0) {
     return 1;                                                    // d = 1, 2 without the window: the per-tile kernel
   } else
+  if (g_dbg_bf16 & 0x100000) AP_P_LAUNCH(0x100000);             // timing only: v_mfma_f32_16x16x32_bf16 pairs in place of 32x32x16
+  else
   switch (g_dbg_bf16 & 0xefff) {
     case 0: AP_P_LAUNCH(0); break;
     case 1: AP_P_LAUNCH(1); break;
