@@ -1,5 +1,6 @@
 """Timing-only variants of the bf16 residual block (tools build): python tools/dbg_resblock_bf16.py [B] [dbg bits ...]
-bit 1 no weight loads in GEMM1, 2 no X loads, 4 no pack, 8 no MFMA in GEMM1, 16 no B-fragment LDS reads in GEMM1.
+bit 1 no weight loads in GEMM1, 2 no X loads, 4 no pack, 8 no MFMA in GEMM1, 16 no B-fragment LDS reads in GEMM1;
+1048576 (0x100000, layers with d >= 64): two v_mfma_f32_16x16x32_bf16 in place of every 32x32x16 (the shape at equal FLOPs).
 Outputs of the variants are wrong by construction; only the times mean anything."""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702
 import sys, ctypes as C, torch
