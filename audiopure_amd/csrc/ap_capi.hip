@@ -100,7 +100,7 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->loaded = false;
   c->slab = nullptr;
   c->slab_bf = nullptr;
-  c->w1p_bf = c->w2p_bf = c->wf1p_bf = nullptr;
+  c->w1p_bf = c->w2p_bf = c->wf1p_bf = c->w1q_bf = nullptr;
   c->slab_s = nullptr;
   c->slab_h = nullptr;
   c->w1p_h = c->w2p_h = nullptr;
@@ -236,10 +236,17 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
   if (c.precision == AP_PREC_BF16) {
     const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
     if (!ctx->slab_bf) {
+#ifdef AP_TOOLS                                                   // + the 16x16x32 GEMM1 image of the tools library's M16 instantiation
+      AP_HIP(hipMalloc(&ctx->slab_bf, (n1 + n2 + (size_t)S * S + n1) * 2));
+#else
       AP_HIP(hipMalloc(&ctx->slab_bf, (n1 + n2 + (size_t)S * S) * 2));
+#endif
       ctx->w1p_bf = ctx->slab_bf;
       ctx->w2p_bf = (char *)ctx->slab_bf + n1 * 2;
       ctx->wf1p_bf = (char *)ctx->slab_bf + (n1 + n2) * 2;     // final conv's first 1x1 (bf16 A-operand image)
+#ifdef AP_TOOLS
+      ctx->w1q_bf = (char *)ctx->slab_bf + (n1 + n2 + (size_t)S * S) * 2;   // GEMM1 image for the 16x16x32 MFMA shape
+#endif
     }
     rc = launch_pack_bf16(ctx, st);
     if (rc) return rc;

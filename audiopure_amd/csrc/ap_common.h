@@ -77,6 +77,7 @@ struct ap_ctx {
   float *w1p, *w2p, *wf1p;  // packed fp32 MFMA A-operand images
   void *w1p_bf, *w2p_bf;    // packed bf16 images (AP_PREC_BF16), own allocation
   void *wf1p_bf;            // final conv's first 1x1 as a bf16 image (same allocation)
+  void *w1q_bf;             // GEMM1 image for v_mfma_f32_16x16x32_bf16 (same allocation, behind wf1p_bf)
   void *slab_bf;
   void *w1p_s, *w2p_s;      // 3-way bf16-split images (AP_PREC_F32_SPLIT), own allocation
   void *slab_s;

@@ -127,12 +127,34 @@ __global__ void pack_wf1_bf16_kernel(const float *__restrict__ wf1f, __bf16 *__r
   out[idx] = (__bf16)wf1f[(size_t)o * S + k];
 }
 
+// GEMM1 image for v_mfma_f32_16x16x32_bf16: [wave C/32][chunk C/32][k-step of 32 = tap 3][rowtile16 4][lane 64][8]; row tiles
+// 0, 1 = tanh rows 0-15, 16-31 of the wave's 32 gate channels, 2, 3 = sigmoid rows; lane l: row l & 15, k = 8 (l >> 4) + jj,
+// i.e. channel ch*32 + 8 (l >> 4) + jj of tap s -- the same k order inside a chunk as the 32x32x16 image (tap-major).
+__global__ void pack_w1q_bf16_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out, int C) {
+  const int NW = C / 32, NCH = C / KC_;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)NW * NCH * 3 * 4 * 64 * 8;
+  if (idx >= total) return;
+  int jj = idx & 7;
+  int lane = (idx >> 3) & 63;
+  int rt = (idx >> 9) & 3;
+  size_t rest = idx >> 11;
+  int tap = rest % 3; rest /= 3;
+  int ch = rest % NCH;
+  int w = rest / NCH;
+  int c = ch * KC_ + 8 * (lane >> 4) + jj;
+  int o = (rt >> 1) * C + 32 * w + 16 * (rt & 1) + (lane & 15);
+  out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + tap];
+}
+
 int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
   const int C = ctx->C, S = ctx->S, NL = ctx->NL;
   for (int n = 0; n < NL; n++) {
     size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
     pack_w1_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1p_bf + n * n1, C);
     pack_w2_bf16_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, (__bf16 *)ctx->w2p_bf + n * n2, C);
+    if (ctx->w1q_bf && C == 256)
+      pack_w1q_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1q_bf + n * n1, C);
   }
   if (ctx->wf1p_bf && S % 64 == 0)
     pack_wf1_bf16_kernel<<<(unsigned)(((size_t)S * S + 255) / 256), 256, 0, st>>>(ctx->wf1f, (__bf16 *)ctx->wf1p_bf, S);
@@ -152,7 +174,14 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // aligned addresses are exact on this chip: tools/micro/unaligned_b128.hip), the clip's last column quad is partly outside
 // it: staged samples are zeroed one by one (the quad's count of valid samples instead of one mask), and the epilogue stores
 // of that quad are one to three dwords.
-template <int DBG, int WS = -1, bool RAG = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
+// M16 (instantiated in the tools library only): GEMM1 on v_mfma_f32_16x16x32_bf16 -- 16-row x 16-column tiles, 32 k per instruction,
+// weight image w1q (pack_w1q), the same X image read with the 16 x 4 lane pattern (224-byte rows: conflict-free), accumulators 4 x 8
+// tiles of 4 registers; gate, GEMM2, epilogues unchanged.  Outputs are BIT-IDENTICAL to the 32x32x16 form (the matrix pipe's fp32
+// accumulation does not depend on how k is grouped into instructions) and the launch is 5-6 % SLOWER (5.44 against 5.12 ms at
+// B = 256: twice the MFMA issue slots, a fragment ring of 32 registers in a kernel that had none to spare); the -6 % of the
+// timing-only substitution (DBG 0x100000: two 16x16x32 on the SAME operand registers per 32x32x16) came from operand reuse, which
+// a real tiling does not have.  DESIGN.md 3.4.
+template <int DBG, int WS = -1, bool RAG = false, bool M16 = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
@@ -165,7 +194,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // 19.4 GB per 512-clip launch (traffic 1.31 -> 1.08 x algorithmic), -3 % time.  DBG 0x4000: default policy everywhere.
   constexpr int NT = (DBG & 0x4000) ? 0 : 2;
   constexpr bool WIN = WS >= 0;
-  constexpr int XBYTES = (PT_ + (WIN ? 4 : 0)) * XS_ * 2;       // 26,624 B per X buffer (WIN: + a scratch column quad), two buffers
+  // M16 without the window: 224-byte rows and no swizzle -- with the 16 x 4 lane pattern of the 16x16x32 B fragment the 16-lane groups
+  // of ds_read_b128 are conflict-free iff the row stride is 14 (or 2) slots of 16 B mod 16 (208 B = 13 slots is 2-way); the
+  // pack's ds_write_b128 is 2-way there (16 LDS cycles against the 13 its register transfer takes: measured free in round 2).
+  // The window variants keep 208-byte rows (their scratch column quad leaves no LDS for longer ones).
+  constexpr int XS = (M16 && !WIN) ? 112 : XS_;
+  constexpr int SWZ = (M16 && !WIN) ? 0 : 1;
+  constexpr int XBYTES = (PT_ + (WIN ? 4 : 0)) * XS * 2;        // 26,624 B per X buffer (WIN: + a scratch column quad), two buffers
   constexpr int GOFF = 2 * XBYTES;
   constexpr int POFF = GOFF + PT_ * GS_ * 2;                   // output patches: 8 waves x 32 x 32 fp32
   constexpr int PTOFF = POFF + NW * 32 * PS_ * 4;              // part_t (C floats)
@@ -211,7 +246,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // cg&3, oct, cg>>2 so a load covers whole 64-B runs per channel row.  Waves 6, 7 repeat tap 2.
   const int xtap = min(wave >> 1, 2);
   const int cg = ((wave & 1) * 4 + (lane >> 4)) * 4 + (lane & 3), oct = (lane >> 2) & 3;
-  const int xcol = 4 * cg, xk = (xtap * KC_ + oct * 8) ^ ((__builtin_popcount(cg & 7) & 1) << 4);   // ^: the X image's 32-byte swizzle (below)
+  int xcol = 4 * cg, xk = (xtap * KC_ + oct * 8) ^ (SWZ * ((__builtin_popcount(cg & 7) & 1) << 4));   // ^: the X image's 32-byte swizzle (below)
+  // (M16: both, and xwb below, are re-derived from the lane id in pack_ptv -- kept from here they are spilled, and a scratch
+  //  reload in the chunk loop is a vector-memory load whose wait drains every request in flight)
 
   if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
   // the bias vectors live in LDS for the whole kernel: fetched per tile from memory they sat behind the previous tile's
@@ -253,18 +290,21 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   Keep keep;
   const int sq = min(wave, 5) * 8 + (lane >> 3), wc4 = lane & 7;
   unsigned xwb[WIN ? 3 : 1][WIN ? 2 : 1];                      // [tap][first / second image quad of the unit's samples]
-  if constexpr (WIN) {
+  auto calc_xwb = [&](int sq_, int wc4_) {
+    if constexpr (WIN) {
 #pragma unroll
-    for (int T = 0; T < 3; T++) {
-      const int qa = sq - 8 + ((T == 2 && WS != 0) ? -1 : 0) - (WS == 0 ? (T - 1) * (d >> 2) : 0);   // image quad of sample 0
+      for (int T = 0; T < 3; T++) {
+        const int qa = sq_ - 8 + ((T == 2 && WS != 0) ? -1 : 0) - (WS == 0 ? (T - 1) * (d >> 2) : 0);   // image quad of sample 0
 #pragma unroll
-      for (int h2 = 0; h2 < 2; h2++) {
-        const int q = qa + h2;
-        const int qc = (q >= 0 && q < PT_ / 4) ? q : PT_ / 4;
-        xwb[T][h2] = (unsigned)(4 * qc * (XS_ * 2) + ((T * 2 * KC_ + wc4 * 8) ^ ((__builtin_popcount(qc & 7) & 1) << 5)));
+        for (int h2 = 0; h2 < 2; h2++) {
+          const int q = qa + h2;
+          const int qc = (q >= 0 && q < PT_ / 4) ? q : PT_ / 4;
+          xwb[T][h2] = (unsigned)(4 * qc * (XS * 2) + ((T * 2 * KC_ + wc4_ * 8) ^ ((__builtin_popcount(qc & 7) & 1) << 5)));
+        }
       }
     }
-  }
+  };
+  calc_xwb(sq, wc4);
   auto x_geom = [&](int t0_in, unsigned &voff, Keep &k) {
     const int t0 = (DBG & 1024) ? 8192 : t0_in;                  // timing-only: every tile stages the same 128 columns of clip 0
     // the lane's geometry is re-derived from a lane id read here (volatile asm: not hoisted out of the tile loop): kept from
@@ -317,6 +357,14 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   auto pack_ptv = [&](int ch) {
     int ln;                                                     // (lane id read here, not kept: see x_geom)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    if constexpr (M16) {                                        // the pack's LDS addresses live from here to the chunk's last piece only
+      if constexpr (WIN) calc_xwb(min(wave, 5) * 8 + (ln >> 3), ln & 7);
+      else {
+        const int cg_ = ((wave & 1) * 4 + (ln >> 4)) * 4 + (ln & 3), oct_ = (ln >> 2) & 3;
+        xcol = 4 * cg_;
+        xk = (xtap * KC_ + oct_ * 8) ^ (SWZ * ((__builtin_popcount(cg_ & 7) & 1) << 4));
+      }
+    }
     if constexpr (WIN) {
       const float4 p0 = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(lds + PTOFF) + (ln & 7) * 4 + ch * KC_);
       ptv8[0] = p0.x; ptv8[1] = p0.y; ptv8[2] = p0.z; ptv8[3] = p0.w;
@@ -350,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
             // place of sample 0 inside its image quad: tap -d: d mod 4; centre: 0; tap +d: (-d) mod 4
             const int a0 = WS == 0 || T == 1 ? 0 : (T == 0 ? WS : 4 - WS);
             const int pos = a0 + i;
-            *reinterpret_cast<uint2 *>(dst + xwb[T][pos >> 2] + (pos & 3) * (XS_ * 2)) = make_uint2(pkq[0], pkq[1]);
+            *reinterpret_cast<uint2 *>(dst + xwb[T][pos >> 2] + (pos & 3) * (XS * 2)) = make_uint2(pkq[0], pkq[1]);
           }
         }
       }
@@ -360,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         pkq[e2] = __builtin_bit_cast(unsigned, __builtin_convertvector(
                                                    f32x2{xr[(2 * e2) * 4 + i] + ptv8[2 * e2],
                                                          xr[(2 * e2 + 1) * 4 + i] + ptv8[2 * e2 + 1]}, bf16x2)) & km;
-      if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS_ + xk) * 2) = pkq;
+      if constexpr (hf == 1) *reinterpret_cast<u32x4 *>(dst + ((xcol + i) * XS + xk) * 2) = pkq;
     }
   };
   auto pack_all = [&](unsigned char *dst, const Keep &keep, int ch) {
@@ -398,7 +446,17 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   // of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}: MI355X_MICROARCH.md, LDS) each hold rows of ONE parity, so the
   // reads stay the conflict-free permutation they were (a swap keyed on a single column bit made them 2-way: measured).
   // Cost: one VGPR (a base for even and one for odd k-steps).
-  const int rdoff = (j * XS_ + 8 * hh) * 2;                     // this lane's B-fragment byte offset inside an X buffer
+  // M16: image [wave][chunk][k32 step 3][rowtile16 4][lane][8] -> fragment fidx of this wave = fidx KB from the wave's base
+  auto ld_w1q = [&](int fidx) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, w1_off + (wave * NCH * 12 + fidx) * 1024, 0));
+  };
+  // M16 B-fragment read: lane (c16 = lane & 15, q4 = lane >> 4) takes k-octet 4 s + q4 of column 16 ct16 + c16; the image's 32-byte
+  // swizzle swaps octets o <-> o ^ 2 in columns whose bits 2..4 have odd parity: bits 2, 3 come from c16, bit 4 from ct16 & 1
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int par16 = __builtin_popcount((c16 >> 2) & 3) & 1;
+  const int rd16e = (c16 * XS) * 2 + ((q4 ^ (SWZ * 2 * par16)) * 16);           // even ct16
+  const int rd16o = (c16 * XS) * 2 + ((q4 ^ (SWZ * 2 * (par16 ^ 1))) * 16);     // odd ct16
+  const int rdoff = (j * XS + 8 * hh) * 2;                      // this lane's B-fragment byte offset inside an X buffer
   const int rdsw = (__builtin_popcount((j >> 2) & 7) & 1) * 32;
   const unsigned char *gb = lds + GOFF + (j * GS_ + 8 * hh) * 2;
   float *patch = reinterpret_cast<float *>(lds + POFF) + wave * 32 * PS_;
@@ -416,11 +474,19 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   constexpr int RING = 3, PK = 3;                                // fragment ring depth (k-steps), k-step that carries the pack (a ring of
                                                                  // six with the pack in k-step 5 -- a chunk of lead for X -- measured +2 %)
   bf16x8 w[RING][2];                                                // GEMM1 fragment ring: k-step ks of a chunk uses w[ks % RING][row tile]
+  bf16x8 wfq[2][4];                                                  // M16: ring of two k-steps of 32 (four 16-row fragments each)
   auto tile_head = [&]() {
+    if constexpr (M16) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) wfq[s2][rt] = ld_w1q(s2 * 4 + rt);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < RING; ks++)
 #pragma unroll
       for (int rt = 0; rt < 2; rt++) w[ks][rt] = ld_w1(ks * 2 + rt);
+    }
     pack_all(lds, keep, 0);
     issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's fourth k-step
   };
@@ -455,6 +521,15 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const int ntile = tile + t_step;
     // ================================================ GEMM1 =========================================================
     f32x16 acc[2][4];
+    f32x4 acq[4][8];                                              // M16: [rowtile16][coltile16]; lane: column c16, rows 4 q4 + reg
+    if constexpr (M16) {
+#pragma unroll
+      for (int rt = 0; rt < 4; rt++) {
+        const f32x4 bv4 = *reinterpret_cast<const f32x4 *>(lds + BOFF + ((rt >> 1) * C + 32 * wave + 16 * (rt & 1) + 4 * q4) * 4);
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) acq[rt][ct] = bv4;
+      }
+    } else
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -488,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     };
     auto rdb = [&](bf16x8 &dst, const unsigned char *xbe, const unsigned char *xbo, int ct, int ks) {   // ks: k-step 0..5 of the chunk
       if constexpr (DBG & 16) asm volatile("" : "=v"(dst));
-      else dst = *reinterpret_cast<const bf16x8 *>(((ks & 1) ? xbo : xbe) + (32 * ct) * (XS_ * 2) + ks * 32);
+      else dst = *reinterpret_cast<const bf16x8 *>(((ks & 1) ? xbo : xbe) + (32 * ct) * (XS * 2) + ks * 32);
     };
     float pre[4][16];
     unsigned evoff[4];                                          // E4 mapping: lane = (row lane>>3 (+8 per step), column quad lane&7)
@@ -576,6 +651,76 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       }
     };
 
+    // M16 chunk: three k-steps of 32 (one per tap), each 8 column tiles x 4 row tiles = 32 MFMAs of 16 cycles.  Four B fragments are
+    // held at a time: a column tile's fragment is re-read for column tile + 4 (then for the next k-step) right behind its four
+    // MFMAs.  A k-step's four weight fragments die with its last column tile and are replaced there by those of the k-step two
+    // on (ring of two k-steps = 32 registers; slot = (3 ch + s) & 1, so the chunk loop runs in pairs with the phase a constant).
+    // The middle k-step carries the next chunk's pack (one piece per column tile), the X request goes out behind the last MFMA.
+    auto chunk16 = [&](const unsigned char *xb, int ch, unsigned char *pdst, auto kind_tag, auto ph_tag) {
+      constexpr int KIND = decltype(kind_tag)::value, PH = decltype(ph_tag)::value;
+      constexpr bool LAST = KIND == 2, WITH_X = KIND == 0;
+      auto rdb16 = [&](bf16x8 &dst, int ct, int s2) {
+        dst = *reinterpret_cast<const bf16x8 *>(xb + ((ct & 1) ? rd16o : rd16e) + (16 * ct) * (XS * 2) + s2 * 64);
+      };
+      bf16x8 bv[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) rdb16(bv[c], c, 0);
+      if constexpr (!(DBG & 0x2000)) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 3; s2++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int slot = (PH + s2) & 1;
+        const bool reload = s2 + 2 < 3 || !LAST;                // k-steps 1, 2 fetch the next chunk's first two
+        const int nf = s2 + 2 < 3 ? (ch * 3 + s2 + 2) * 4 : ((ch + 1) * 3 + s2 + 2 - 3) * 4;
+        if (s2 == 1) {
+          if constexpr (!(DBG & 0x2000)) __builtin_amdgcn_s_setprio(0);
+          if constexpr (!LAST) pack_ptv(ch + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 8; ct++) {
+#pragma unroll
+          for (int rt = 0; rt < 4; rt++) {
+            acq[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfq[slot][rt], bv[ct & 3], acq[rt][ct], 0, 0, 0);
+            if (ct == 7 && reload) wfq[slot][rt] = ld_w1q(nf + rt);
+            if constexpr (!LAST) {
+              if (s2 == 1 && rt == 1) {
+                if (ct == 0) pack_piece(pdst, keep, I0{}, I0{});
+                if (ct == 1) pack_piece(pdst, keep, I0{}, I1{});
+                if (ct == 2) pack_piece(pdst, keep, I1{}, I0{});
+                if (ct == 3) pack_piece(pdst, keep, I1{}, I1{});
+                if (ct == 4) pack_piece(pdst, keep, I2{}, I0{});
+                if (ct == 5) pack_piece(pdst, keep, I2{}, I1{});
+                if (ct == 6) pack_piece(pdst, keep, I3{}, I0{});
+                if (ct == 7) pack_piece(pdst, keep, I3{}, I1{});
+              }
+            }
+            if (rt == 3) {
+              if (ct < 4) rdb16(bv[ct & 3], ct + 4, s2);
+              else if (s2 < 2) rdb16(bv[ct & 3], ct - 4, s2 + 1);
+            }
+            if constexpr (WITH_X) {
+              if (s2 == 2 && ct == 7 && rt == 3) issue_x(hrs, xvoff, ch + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    };
+    if constexpr (M16) {
+      static_assert(!M16 || NCH == 8, "paired chunk schedule");
+#pragma unroll 1
+      for (int ch = 0; ch < NCH - 2; ch += 2) {
+        chunk16(lds, ch, lds + XBYTES, I0{}, I0{});
+        __syncthreads();
+        chunk16(lds + XBYTES, ch + 1, lds, I0{}, I1{});
+        __syncthreads();
+      }
+      chunk16(lds, NCH - 2, lds + XBYTES, I1{}, I0{});
+      __syncthreads();
+      chunk16(lds + XBYTES, NCH - 1, nullptr, I2{}, I1{});
+    } else {
 #pragma unroll 1
     for (int ch = 0; ch < NCH - 2; ch++) {
       const unsigned char *xbe = lds + (ch & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
@@ -595,6 +740,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       const unsigned char *xbe = lds + ((NCH - 1) & 1) * XBYTES + rdoff + rdsw, *xbo = xbe - 2 * rdsw;
       chunk(xbe, xbo, NCH - 1, nullptr, I2{});
       mark(25);
+    }
     }
 
     // ================================================ gate ==========================================================
@@ -650,6 +796,25 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       constexpr int ct = decltype(ct_tag)::value;
       int ln;                                                    // (lane id read here, not kept: see x_geom)
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      if constexpr (M16) {                                       // the two 16-column tiles of this 32-column tile x both channel halves
+        const int c16 = ln & 15, q4 = ln >> 4;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++)
+#pragma unroll
+          for (int rtp = 0; rtp < 2; rtp++) {
+            const f32x4 a4 = acq[rtp][2 * ct + h2], b4 = acq[rtp + 2][2 * ct + h2];
+            unsigned pk[2];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+              const f32x2 a2 = {a4[e], a4[e + 1]}, b2 = {b4[e], b4[e + 1]};
+              const f32x2 g2 = (DBG & 32) ? a2 + b2 : gate_fast2(a2, b2);
+              pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(g2, bf16x2));
+            }
+            *reinterpret_cast<uint2 *>(lds + GOFF + ((32 * ct + 16 * h2 + c16) * GS_ + 32 * wave + 16 * rtp + 4 * q4) * 2) = make_uint2(pk[0], pk[1]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+      }
       const int j = ln & 31, hh = ln >> 5;
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
@@ -842,7 +1007,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   const char *wlo = (const char *)ctx->w1p_bf < (const char *)ctx->w2p_bf ? (const char *)ctx->w1p_bf : (const char *)ctx->w2p_bf;
   const unsigned w1_off = (unsigned)((const char *)ctx->w1p_bf - wlo + layer * n1 * 2);
   const unsigned w2_off = (unsigned)((const char *)ctx->w2p_bf - wlo + layer * n2 * 2);
-  const unsigned wbytes = (unsigned)((size_t)ctx->NL * (n1 + n2) * 2);
+  const unsigned wbytes = (unsigned)(((size_t)ctx->NL * (n1 + n2) + (size_t)S * S + (ctx->w1q_bf ? (size_t)ctx->NL * n1 : 0)) * 2);   // the whole bf16 slab
   const float *blo = ctx->b1 < ctx->b2 ? ctx->b1 : ctx->b2;
   const float *bhi = ctx->b1 < ctx->b2 ? ctx->b2 : ctx->b1;
   const unsigned b1_off = (unsigned)((ctx->b1 - blo + (size_t)layer * 2 * C) * 4);
@@ -869,6 +1034,11 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     else AP_P_LAUNCH_WIN(0, 2);
   } else if (ws > 0) {
     return 1;                                                    // d = 1, 2 without the window: the per-tile kernel
+  } else
+  if ((g_dbg_bf16 & 0x200000) && ctx->w1q_bf) {                  // tools bit 0x200000: GEMM1 on v_mfma_f32_16x16x32_bf16 (exact; A/B)
+    const unsigned w1q_off = (unsigned)((const char *)ctx->w1q_bf - wlo + layer * n1 * 2);
+    resblock_bf16p_kernel<0, -1, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1q_off, w2_off, blo,
+                                                                            bbytes, b1_off, b2_off, L, d, accumulate, ntiles, nblk);
   } else
   if (g_dbg_bf16 & 0x100000) AP_P_LAUNCH(0x100000);             // timing only: v_mfma_f32_16x16x32_bf16 pairs in place of 32x32x16
   else
