@@ -107,3 +107,46 @@ def test_mel_classifier_pipeline_end_to_end(dev):
     with torch.no_grad():
         ref = clf(O.melspec_db(xp))
     assert rel_err(logits.numpy(), ref.numpy()) < 5e-3        # mel dB amplifies tiny spectral differences
+
+
+def test_split_k_and_few_output_paths_match_torch_and_are_deterministic(dev):
+    """Round-3 paths of ap_conv2d_fwd: split-K for layers with too few output tiles (the UNet's 4 x 4 maps,
+    improved_diffusion/unet.py:60-104 levels; partial sums in the caller's workspace, slices summed in order) with and
+    without the workspace, with bias + residual; and the one-thread-per-pixel kernel for Cout <= 4 (the UNet's output
+    convolution, unet.py:432-436)."""
+    from audiopure_amd import _native as N
+    lib = N.lib()
+    torch.manual_seed(3)
+
+    def conv(x, w, b, res, pad, use_ws):
+        Cout, Cin, kh, kw = w.shape
+        wT = torch.empty(lib.ap_conv2d_packed_elems(Cout, Cin, kh, kw, 1), device=dev)
+        N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), Cout, Cin, kh, kw, 1, N.stream()))
+        if use_ws:
+            N.use_conv_workspace(dev)
+        else:
+            N.check(lib.ap_conv2d_set_workspace(None, 0))
+        B, _, H, W = x.shape
+        out = torch.empty(B, Cout, H + 2 * pad - kh + 1, W + 2 * pad - kw + 1, device=dev)
+        N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(res), N.ptr(out), B, Cin, H, W, Cout, kh, kw, 1, pad, 1, 0,
+                                  Cin, 0, N.stream()))
+        return out
+
+    # 4 x 4 map, K = 256 * 9 = 2304 (144 chunks), 256 output channels: the split-K shape of BASELINE configs[4]
+    x = torch.randn(64, 256, 4, 4, device=dev)
+    w = torch.randn(256, 256, 3, 3, device=dev) * 0.03
+    b = torch.randn(256, device=dev)
+    res = torch.randn(64, 256, 4, 4, device=dev)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1) + res
+    split_a, split_b, plain = conv(x, w, b, res, 1, True), conv(x, w, b, res, 1, True), conv(x, w, b, res, 1, False)
+    assert torch.equal(split_a, split_b)                                     # slices summed in a fixed order
+    assert rel_err(split_a.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    assert rel_err(plain.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    # Cout = 1 and 3: the few-output kernel, with padding and a ragged pixel count
+    for cout in (1, 3):
+        x = torch.randn(5, 128, 9, 7, device=dev)
+        w = torch.randn(cout, 128, 3, 3, device=dev) * 0.05
+        b = torch.randn(cout, device=dev)
+        got = conv(x, w, b, None, 1, True)
+        assert rel_err(got.cpu().numpy(), torch.nn.functional.conv2d(x, w, b, padding=1).cpu().numpy()) < 5e-6
+    N.use_conv_workspace(dev)
