@@ -669,7 +669,6 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s2 = 0; s2 < 3; s2++) {
-        constexpr int dummy = 0; (void)dummy;
         const int slot = (PH + s2) & 1;
         const bool reload = s2 + 2 < 3 || !LAST;                // k-steps 1, 2 fetch the next chunk's first two
         const int nf = s2 + 2 < 3 ? (ch * 3 + s2 + 2) * 4 : ((ch + 1) * 3 + s2 + 2 - 3) * 4;
