@@ -73,7 +73,10 @@ class RobustCertificate():
     def smooth_predict(self, x: torch.Tensor, num_sampling: int = 100, sigma=0.25, batch_size=64):
         """(RobustCertificate is no nn.Module and accepts CPU input, so the classifier's device is made current here: streams,
         allocations and every native launch of the body bind to it.)"""
-        with torch.cuda.device(next(self.classifier.parameters()).device):
+        dev = next(self.classifier.parameters()).device
+        if dev.type != "cuda":
+            raise N.NativeError("RobustCertificate needs its classifier on a HIP device (.cuda()); there is no CPU path")
+        with torch.cuda.device(dev):
             return self._smooth_predict(x, num_sampling, sigma, batch_size)
 
     def _smooth_predict(self, x: torch.Tensor, num_sampling: int = 100, sigma=0.25, batch_size=64):
