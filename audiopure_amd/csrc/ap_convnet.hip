@@ -278,7 +278,10 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
 // 32-bit VGPR offset computed once per chunk and the row / fragment step in the SCALAR offset, padding taps read through an
 // out-of-range offset (returns 0) -- the 64-bit per-load address arithmetic and the selects of the pointer form were 2.9 VALU
 // + 2 SALU instructions per MFMA, and the chip held 1.95 GHz under them against 2.38 under the fused block.
-template <int BM, int BN, bool BUF = true>
+// P1 (1 x 1, stride 1, no padding, H W % 4 == 0: the attention qkv / proj convolutions, skip connections, ResNeXt's pointwise
+// layers): the "gather" is a plain row of pixels, so a thread stages four consecutive pixels of a channel with ONE 16-byte
+// load and one ds_write_b128 -- two loads per thread and chunk instead of eight.
+template <int BM, int BN, bool BUF = true, bool P1 = false>
 __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag, unsigned x_bytes,
                                                                  unsigned a_bytes) {
   // 2 x 2 waves, each (BM/2 rows x BN/2 columns): BM x BN = 128 x 128, 128 x 64 (layers with few tiles), 64 x 128
@@ -323,7 +326,25 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
     const int mt = min((m0 >> 5) + NX * wm + x_, MT - 1);
     af_off[x_] = (unsigned)((((size_t)g * MT + mt) * KQ * 64 + lane) * 16);
   }
+  // P1 staging geometry: thread = (pixel quad nq of BN / 4, chunk row kq1 of R1 = 1024 / BN), NP1 = 16 / R1 passes
+  constexpr int R1 = 1024 / BN, NP1 = BK / R1;
+  f32x4 br4[P1 ? NP1 : 1];
+  const int nq1 = tid % (BN / 4), kq1 = tid / (BN / 4);
+  unsigned voff1 = 0x80000000u;
+  if constexpr (P1) {
+    const int n4 = n0 + 4 * nq1;                                // four pixels of one image (H W % 4 == 0), inside N or outside as a whole
+    if (n4 < N) {
+      const int b4 = n4 / HoWo, p4 = n4 - b4 * HoWo;
+      voff1 = (unsigned)((((size_t)b4 * a.x_cstride + a.x_coff + (size_t)g * Cg + kq1) * HW + p4) * 4);
+    }
+  }
   auto load_b = [&](int c) {                                   // chunk c = (tap r, channels c0 .. c0+15)
+    if constexpr (P1) {
+#pragma unroll
+      for (int i = 0; i < NP1; i++)
+        br4[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, voff1, (c * BK + R1 * i) * HW * 4, 0));
+      return;
+    }
     const int r = c / CPT, c0 = (c - r * CPT) * BK;
     const int ky = r / a.kw, kx = r - ky * a.kw;
     const int iy = iy0 + ky * a.dil_h, ix = ix0 + kx * a.dil_w;
@@ -354,6 +375,11 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
       }
   };
   auto store_b = [&](int buf) {
+    if constexpr (P1) {
+#pragma unroll
+      for (int i = 0; i < NP1; i++) *reinterpret_cast<f32x4 *>(&Bs[buf][kq1 + R1 * i][4 * nq1]) = br4[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < EPT; i++) Bs[buf][kq + KSTEP * i][nl] = br[i];
   };
@@ -973,6 +999,7 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     const size_t xbytes = (size_t)B * x_cstride * H * W * sizeof(float);
     const size_t abytes = conv_frag_elems(Cout, Cin / groups, kh, kw, groups) * sizeof(float);
     const bool buf = xbytes < ((size_t)1 << 31) && abytes < ((size_t)1 << 31);
+    const bool p1 = kh == 1 && kw == 1 && stride == 1 && pad == 0 && !one_d && (H * W) % 4 == 0;   // pointwise: 16-byte staging
     if (splith) {                                               // two fp16 parts per operand, three partial products
       const void *hfrag = afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups) +
                           conv_split_floats(Cout, Cin / groups, kh, kw, groups);
@@ -1004,7 +1031,8 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     } else if (tiles128 >= g_conv_frag_min_tiles) {
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
       *cls = 0;
-      if (buf) conv2d_f32_big2_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      if (buf && p1) conv2d_f32_big2_kernel<128, 128, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      else if (buf) conv2d_f32_big2_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else conv2d_f32_big2_kernel<128, 128, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
     } else if (buf && groups == 1 && !split && !splith && tiles128 * 2 < 384 && kh * kw * (Cin / 16) >= 32 && g_conv_ws &&
                2 * (size_t)B * Cout * a.Ho * a.Wo * sizeof(float) <= g_conv_ws_bytes) {
@@ -1031,7 +1059,8 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     } else if (((N + 63) / 64) * ((Mg + 127) / 128) * (long long)groups >= 192) {   // few tiles (low-resolution layers): 128 x 64
       dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 127) / 128), (unsigned)groups);
       *cls = 2;
-      if (buf) conv2d_f32_big2_kernel<128, 64, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      if (buf && p1) conv2d_f32_big2_kernel<128, 64, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
+      else if (buf) conv2d_f32_big2_kernel<128, 64, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else conv2d_f32_big2_kernel<128, 64, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
     } else {                                                    // fewer still (4 x 4 maps, the embedding's linear layers): 64 x 64,
       dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 63) / 64), (unsigned)groups);   // twice the workgroups for 256 CUs
