@@ -783,6 +783,22 @@ __global__ void copy_channels_kernel(const float *__restrict__ src, float *__res
   dst[((size_t)n * d_cs + d_co + c) * HW + p] = src[((size_t)n * s_cs + s_co + c) * HW + p];
 }
 
+// the same slice copy as a 2-D copy: the C channels of one sample are one contiguous run of C HW floats on both sides, moved
+// with 16-byte accesses, four per thread (blockIdx.y = the sample)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float *__restrict__ src, float *__restrict__ dst, unsigned row4,
+                                                        size_t s_row, size_t d_row) {
+  const f32x4 *sp = (const f32x4 *)(src + blockIdx.y * s_row);
+  f32x4 *dp = (f32x4 *)(dst + blockIdx.y * d_row);
+  const unsigned i0 = blockIdx.x * 1024 + threadIdx.x;
+  f32x4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (i0 + u * 256 < row4) v[u] = sp[i0 + u * 256];
+#pragma unroll
+  for (int u = 0; u < 4; u++)
+    if (i0 + u * 256 < row4) dp[i0 + u * 256] = v[u];
+}
+
 // max / average pooling (count_include_pad semantics of F.avg_pool2d default; no padding used by the reference nets)
 __global__ void pool2d_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int Ho, int Wo, int k,
                               int stride, int pad, int is_max, size_t total) {
@@ -1116,6 +1132,15 @@ extern "C" int ap_copy_channels(const float *src, float *dst, int B, int C, int 
                                 int d_coff, void *stream) {
   if (!src || !dst || B < 1 || C < 1 || HW < 1) { set_error("ap_copy_channels: bad argument"); return -22; }
   size_t total = (size_t)B * C * HW;
+  const size_t row = (size_t)C * HW, s_row = (size_t)s_cstride * HW, d_row = (size_t)d_cstride * HW;
+  const float *s0 = src + (size_t)s_coff * HW;
+  float *d0 = dst + (size_t)d_coff * HW;
+  if (row % 4 == 0 && s_row % 4 == 0 && d_row % 4 == 0 && (((uintptr_t)s0 | (uintptr_t)d0) & 15) == 0 && row / 4 < (1u << 31) && B < 65536) {
+    const unsigned row4 = (unsigned)(row / 4);
+    copy_rows_kernel<<<dim3((row4 + 1023) / 1024, (unsigned)B), 256, 0, (hipStream_t)stream>>>(s0, d0, row4, s_row, d_row);
+    AP_HIP(hipGetLastError());
+    return 0;
+  }
   copy_channels_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, dst, C, HW, s_cstride, s_coff,
                                                                                     d_cstride, d_coff, total);
   AP_HIP(hipGetLastError());
@@ -1179,6 +1204,74 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float *__restrict_
     if (act == 2) o = silu_f(o);
     else if (act == 1) o = fmaxf(o, 0.f);
     yp[i] = o;
+  }
+}
+
+// One pass over HBM: the (sample, group) slab -- cpg * HW contiguous floats -- is read once with 16-byte loads, stays in
+// registers through the two-pass statistics (mean, then the variance of the deviations: the same arithmetic as above) and is
+// written once.  T threads serve one slab: a wave when it has <= 1024 floats (four slabs per block), the block otherwise;
+// NV = 16-byte vectors per thread.  HBM-bound: 8 bytes per element.
+template <int T, int NV>
+__global__ __launch_bounds__(256) void groupnorm_reg_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, const float *__restrict__ ss,
+                                                            float *__restrict__ y, int C, int HW, int groups, float eps,
+                                                            int act, int slabs) {
+  __shared__ float red[8];
+  const int slab = blockIdx.x * (256 / T) + (int)threadIdx.x / T, lane = (int)threadIdx.x % T;
+  const bool live = slab < slabs;
+  const int b = slab / groups, g = slab % groups, cpg = C / groups, n = cpg * HW, n4 = n >> 2;
+  const f32x4 *xp = (const f32x4 *)(x + (size_t)slab * n);
+  f32x4 *yp = (f32x4 *)(y + (size_t)slab * n);
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; u++) {
+    const int i = lane + u * T;
+    if (live && i < n4) {
+      v[u] = xp[i];
+      s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+  }
+  auto total = [&](float a, int slot) -> float {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (T == 64) return a;
+    if ((threadIdx.x & 63) == 0) red[slot * 4 + (threadIdx.x >> 6)] = a;
+    __syncthreads();
+    return (red[slot * 4] + red[slot * 4 + 1]) + (red[slot * 4 + 2] + red[slot * 4 + 3]);
+  };
+  const float mean = total(s, 0) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < NV; u++)
+    if (live && lane + u * T < n4)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float dlt = v[u][e] - mean;
+        q = __builtin_fmaf(dlt, dlt, q);
+      }
+  const float rstd = 1.0f / sqrtf(total(q, 1) / (float)n + eps);
+#pragma unroll
+  for (int u = 0; u < NV; u++) {
+    const int i = lane + u * T;
+    if (live && i < n4) {
+      const int c = g * cpg + (i * 4) / HW;                       // HW % 4 == 0: the four elements share a channel
+      float ga = rstd * gamma[c], be = beta[c] - mean * ga;
+      if (ss) {
+        const float sc = 1.0f + ss[(size_t)b * 2 * C + c];
+        ga *= sc;
+        be = be * sc + ss[(size_t)b * 2 * C + C + c];
+      }
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float r = __builtin_fmaf(v[u][e], ga, be);
+        if (act == 2) r = silu_f(r);
+        else if (act == 1) r = fmaxf(r, 0.f);
+        o[e] = r;
+      }
+      yp[i] = o;
+    }
   }
 }
 
@@ -1366,7 +1459,22 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__rest
 extern "C" int ap_groupnorm_nchw(const float *x, const float *gamma, const float *beta, const float *scale_shift, float *y,
                                  int B, int C, int HW, int groups, float eps, int act, void *stream) {
   if (!x || !gamma || !beta || !y || B < 1 || C < 1 || HW < 1 || groups < 1 || C % groups) { set_error("ap_groupnorm_nchw: bad argument"); return -22; }
-  groupnorm_kernel<<<(unsigned)(B * groups), 256, 0, (hipStream_t)stream>>>(x, gamma, beta, scale_shift, y, C, HW, groups, eps, act);
+  hipStream_t st = (hipStream_t)stream;
+  const int slabs = B * groups, n = (C / groups) * HW, n4 = n / 4;
+  const bool vec = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0 && !g_conv_no_frag;
+#define AP_GN(T, NV)                                                                                                          \
+  groupnorm_reg_kernel<T, NV><<<(unsigned)((slabs + 256 / T - 1) / (256 / T)), 256, 0, st>>>(x, gamma, beta, scale_shift, y, C, HW, \
+                                                                                            groups, eps, act, slabs)
+  if (vec && n4 <= 64) AP_GN(64, 1);
+  else if (vec && n4 <= 128) AP_GN(64, 2);
+  else if (vec && n4 <= 256) AP_GN(64, 4);
+  else if (vec && n4 <= 512) AP_GN(256, 2);
+  else if (vec && n4 <= 1024) AP_GN(256, 4);
+  else if (vec && n4 <= 2048) AP_GN(256, 8);
+  else if (vec && n4 <= 3072) AP_GN(256, 12);
+  else if (vec && n4 <= 4096) AP_GN(256, 16);
+  else groupnorm_kernel<<<(unsigned)slabs, 256, 0, st>>>(x, gamma, beta, scale_shift, y, C, HW, groups, eps, act);
+#undef AP_GN
   AP_HIP(hipGetLastError());
   return 0;
 }

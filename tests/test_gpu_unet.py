@@ -41,6 +41,33 @@ def test_primitives_match_torch(dev):
     xd, gd, bd, sd_ = x.to(dev), g.to(dev), b.to(dev), ss.to(dev)      # keep the device copies alive across the launch
     N.check(lib.ap_groupnorm_nchw(N.ptr(xd), N.ptr(gd), N.ptr(bd), N.ptr(sd_), N.ptr(y), 3, 64, 64, 32, 1e-5, 2, N.stream()))
     assert rel_err(y.cpu().numpy(), ref.numpy()) < 3e-6
+    # every form of the one-pass kernel (a wave or the block per (sample, group) slab, 1 .. 16 vectors per thread), the slab
+    # count not a multiple of the slabs per block, and the three-pass fallback (H W % 4 != 0, slab > 16384 floats)
+    for (B, C_, H, W, G, act, use_ss) in ((3, 64, 2, 2, 32, 2, True), (5, 64, 4, 4, 32, 2, False), (3, 96, 8, 8, 32, 0, True),
+                                          (2, 128, 16, 8, 32, 1, False), (2, 64, 32, 32, 32, 2, True), (2, 128, 32, 32, 32, 2, True),
+                                          (2, 256, 32, 32, 32, 0, False), (1, 384, 32, 32, 32, 2, True), (1, 96, 64, 64, 32, 2, True),
+                                          (1, 64, 64, 48, 8, 2, False), (2, 64, 5, 5, 32, 2, True), (1, 32, 96, 96, 4, 2, True)):
+        x = torch.from_numpy(synth.uniform(f"gnx{C_}{H}{W}", (B, C_, H, W), 1, -2, 2)) + 0.7
+        g, b = torch.from_numpy(synth.uniform("gng", (C_,), 1, 0.5, 1.5)), torch.from_numpy(synth.uniform("gnb", (C_,), 1))
+        ss = torch.from_numpy(synth.uniform("gns", (B, 2 * C_), 1))
+        ref = F.group_norm(x, G, g, b, 1e-5)
+        if use_ss:
+            ref = ref * (1 + ss[:, :C_, None, None]) + ss[:, C_:, None, None]
+        ref = ref * torch.sigmoid(ref) if act == 2 else ref.relu() if act == 1 else ref
+        xd, gd, bd, sd_ = x.to(dev), g.to(dev), b.to(dev), ss.to(dev)
+        y = torch.full_like(xd, float("nan"))
+        N.check(lib.ap_groupnorm_nchw(N.ptr(xd), N.ptr(gd), N.ptr(bd), N.ptr(sd_) if use_ss else None, N.ptr(y), B, C_, H * W, G, 1e-5,
+                                      act, N.stream()))
+        assert rel_err(y.cpu().numpy(), ref.numpy()) < 3e-6, (B, C_, H, W, G, act, use_ss)
+    # channel-slice copy (torch.cat / slices): the 16-byte 2-D form and the element form (H W = 25, an unaligned offset)
+    for (B, C_, HW, scs, sco, dcs, dco) in ((3, 8, 64, 8, 0, 20, 12), (2, 5, 1024, 9, 3, 5, 0), (2, 6, 25, 7, 1, 9, 2), (2, 3, 6, 4, 1, 7, 3),
+                                            (4, 10, 1, 16, 4, 12, 1), (2, 8, 1, 16, 4, 12, 4)):
+        src = torch.from_numpy(synth.uniform(f"cp{C_}{HW}", (B, scs, HW), 1)).to(dev)
+        dst = torch.zeros((B, dcs, HW), device=dev)
+        N.check(lib.ap_copy_channels(N.ptr(src), N.ptr(dst), B, C_, HW, scs, sco, dcs, dco, N.stream()))
+        ref = torch.zeros_like(dst)
+        ref[:, dco:dco + C_] = src[:, sco:sco + C_]
+        assert torch.equal(dst, ref), (B, C_, HW, scs, sco, dcs, dco)
     for ch, T, heads in ((16, 256, 2), (64, 64, 4), (32, 100, 1), (64, 256, 3)):     # the ch = 64 cases run on the MFMA
         qkv = torch.from_numpy(synth.uniform(f"qkv{ch}", (2, heads * 3 * ch, T), 1, -1.5, 1.5))
         q, k, v = torch.split(qkv.reshape(2 * heads, 3 * ch, T), ch, dim=1)
