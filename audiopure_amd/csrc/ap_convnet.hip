@@ -1385,22 +1385,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const float *__restrict_
 //      the pair of keys the two lane halves hold in the same register), A = V from a transposed LDS image (lane = channel).
 // One workgroup per (sample, head), one wave per 32-query block.
 template <int NT>                                               // NT = T / 32 key tiles (2 or 8)
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ out,
-                                                             float scale2) {
-  constexpr int CH = 64, T = 32 * NT, VS = CH + 1;
+__global__ __launch_bounds__(NT >= 8 ? 512 : 256) void attention_mfma_kernel(const float *__restrict__ qkv, float *__restrict__ out,
+                                                                             float scale2) {
+  constexpr int CH = 64, T = 32 * NT, VS = CH + 1, NTHR = NT >= 8 ? 512 : 256;   // T = 256: eight waves, two per SIMD -- one
+  // wave's softmax (256 exp per lane) and operand latencies run under the other's MFMAs
   extern __shared__ float sm[];
   float *ks = sm;                                               // [CH][T]
   float *vt = sm + CH * T;                                      // [T][CH + 1]
   const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hh = lane >> 5;
   const float *base = qkv + (size_t)bh * 3 * CH * T;
-  for (int i = tid; i < CH * T; i += 256) {
+  for (int i = tid; i < CH * T; i += NTHR) {
     ks[i] = base[(size_t)CH * T + i];
     const int c = i / T, t = i - c * T;
     vt[t * VS + c] = base[(size_t)2 * CH * T + i];
   }
   __syncthreads();
-  for (int qb = wave; qb < NT; qb += 4) {
+  for (int qb = wave; qb < NT; qb += NTHR / 64) {
     float q[CH / 2];
 #pragma unroll
     for (int s2 = 0; s2 < CH / 2; s2++) q[s2] = base[(size_t)(2 * s2 + hh) * T + 32 * qb + j] * scale2;
@@ -1518,7 +1519,7 @@ extern "C" int ap_attention_qkv(const float *qkv, float *out, int B, int C, int 
       attr2 = true;
     }
     if (T == 64) attention_mfma_kernel<2><<<grid, 256, sm2, st>>>(qkv, out, scale2);
-    else attention_mfma_kernel<8><<<grid, 256, sm2, st>>>(qkv, out, scale2);
+    else attention_mfma_kernel<8><<<grid, 512, sm2, st>>>(qkv, out, scale2);
     AP_HIP(hipGetLastError());
     return 0;
   }
