@@ -296,9 +296,14 @@ extern "C" int ap_ctx_get_folded(ap_ctx *ctx, int which, int layer, float *out_d
 }
 
 // workspace: h_a [B C L] | h_b [B C L] | skip [B S L] | x_a [B L] | x_b [B L] | part_t [NL C + Eout]
+//            | tools builds, AP_PREC_BF16: ub_a, ub_b [B][C/32][L][32] bf16 (the operand-image experiment: ap_resblock_bf16p.hip, UB)
+#ifdef AP_TOOLS
+namespace ap { extern int g_dbg_bf16; }
+#endif
 namespace {
 struct Ws {
   float *ha, *hb, *skip, *xa, *xb, *pt;
+  void *uba, *ubb;
   size_t bytes;
 };
 inline size_t al(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -313,6 +318,14 @@ Ws carve(const ap_ctx *ctx, void *base, int B, int L) {
   w.xa = p; p += xl;
   w.xb = p; p += xl;
   w.pt = p; p += pt;
+  w.uba = w.ubb = nullptr;
+#ifdef AP_TOOLS
+  if (ctx->cfg.precision == AP_PREC_BF16) {
+    const size_t ub = al(((size_t)B * ctx->C * L + 1) / 2);
+    w.uba = p; p += ub;
+    w.ubb = p; p += ub;
+  }
+#endif
   w.bytes = (size_t)((char *)p - (char *)base);
   return w;
 }
@@ -333,6 +346,24 @@ int run_net(ap_ctx *ctx, const float *x, float step, const Ws &w, int B, int L, 
   rc = launch_init_conv(ctx, x, w.ha, B, L, st);
   if (rc) return rc;
   float *hin = w.ha, *hout = w.hb;
+#ifdef AP_TOOLS
+  // tools bit 0x400000 (tools/ab_bf16_ub.py): each layer hands the next one its bf16 operand image -- bit-identical, 3 % slower
+  // (the block runs at the board's power cap; the image's extra stores cost more than its staging saves: DESIGN.md 3.4)
+  if (w.uba != nullptr && (ap::g_dbg_bf16 & 0x400000)) {
+    rc = launch_make_ub(w.ha, w.pt, w.uba, B, ctx->C, L, st);
+    if (rc) return rc;
+    void *uin = w.uba, *uout = w.ubb;
+    for (int n = 0; n < ctx->NL; n++) {
+      const bool last = n + 1 == ctx->NL;
+      const UbArgs ub = {uin, last ? nullptr : uout, w.pt + (size_t)(last ? n : n + 1) * ctx->C};
+      rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, hout, w.skip, n > 0, B, L, st, nullptr, &ub);
+      if (rc) return rc;
+      float *t = hin; hin = hout; hout = t;
+      void *u = uin; uin = uout; uout = u;
+    }
+    return 0;
+  }
+#endif
   for (int n = 0; n < ctx->NL; n++) {
     rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, hout, w.skip, n > 0, B, L, st);
     if (rc) return rc;

@@ -126,8 +126,16 @@ namespace ap {
 int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st);
 int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st);
 int launch_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, hipStream_t st);
+// AP_PREC_BF16 chain form: bf16 images of u = h + part_t, [clip][C / 32][L][32] (ap_resblock_bf16p.hip, UB); `out` is null on the
+// net's last layer, `pt_next` is the next layer's part_t
+struct UbArgs {
+  const void *in;
+  void *out;
+  const float *pt_next;
+};
+int launch_make_ub(const float *h, const float *pt, void *ub, int B, int C, int L, hipStream_t st);
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr);
+                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr, const UbArgs *ub = nullptr);
 int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st);
@@ -138,9 +146,9 @@ int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, flo
                              float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                              hipStream_t st);                    // returns 1 if the shape is not served (caller: fp32 kernel)
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                         int accumulate, int B, int L, hipStream_t st);
+                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                          int accumulate, int B, int L, hipStream_t st);   // persistent form; returns 1 if the shape is not served
+                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr);   // persistent form; returns 1 if the shape is not served
 int launch_resblock_bf16w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);   // one wave per SIMD; returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);

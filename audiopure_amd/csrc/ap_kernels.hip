@@ -529,7 +529,7 @@ static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
 #endif
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st, float *aout) {
+                    int accumulate, int B, int L, hipStream_t st, float *aout, const UbArgs *ub) {
   if (aout && ctx->cfg.precision != AP_PREC_F32) {
     set_error("ap_resblock_fwd_save: fp32 arithmetic only (the other modes recompute the pre-gate activations)");
     return -22;
@@ -549,7 +549,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
       AP_HIP(hipEventRecord(e0, st));
     }
     int rc = ctx->cfg.precision == AP_PREC_BF16
-                 ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st)
+                 ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub)
              : ctx->cfg.precision == AP_PREC_F32_SPLIT
                  ? launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st)
                  : launch_resblock_splith(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);

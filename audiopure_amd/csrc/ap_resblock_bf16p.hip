@@ -163,6 +163,35 @@ int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
 }
 
 #ifdef AP_TOOLS
+// u = bf16(h + part_t) as the chain's operand image [clip][C / 32][L][32] (layer 0 of a sweep; every later layer's image is
+// written by the previous layer's epilogue).  Lane = (sample, channel octet): eight reads L apart (each 64 B per 16 lanes),
+// one 16-byte store; a wave writes 1 KB contiguous.
+__global__ __launch_bounds__(256) void make_ub_kernel(const float *__restrict__ h, const float *__restrict__ pt,
+                                                      __bf16 *__restrict__ ub, int C, int L, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // ((clip * C/32 + chunk) * L + t) * 4 + octet
+  if (idx >= total) return;
+  const int oct = (int)(idx & 3);
+  const size_t row = idx >> 2;                                    // (clip * C/32 + chunk) * L + t
+  const int t = (int)(row % (size_t)L);
+  const size_t bc = row / (size_t)L;                              // clip * C/32 + chunk
+  const int c0 = (int)(bc % (size_t)(C / 32)) * 32 + oct * 8;
+  const float *hp = h + ((bc / (size_t)(C / 32)) * C + c0) * (size_t)L + t;
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const f32x2 v2 = {hp[(size_t)(2 * e) * L] + pt[c0 + 2 * e], hp[(size_t)(2 * e + 1) * L] + pt[c0 + 2 * e + 1]};
+    o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
+  }
+  reinterpret_cast<u32x4 *>(ub)[idx] = o;
+}
+
+int launch_make_ub(const float *h, const float *pt, void *ub, int B, int C, int L, hipStream_t st) {
+  const size_t total = (size_t)B * (C / 32) * L * 4;
+  make_ub_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(h, pt, (__bf16 *)ub, C, L, total);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
 __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [workgroup][wave][64] s_memtime stamps of one tile
 #endif
 
@@ -181,31 +210,49 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // B = 256: twice the MFMA issue slots, a fragment ring of 32 registers in a kernel that had none to spare); the -6 % of the
 // timing-only substitution (DBG 0x100000: two 16x16x32 on the SAME operand registers per 32x32x16) came from operand reuse, which
 // a real tiling does not have.  DESIGN.md 3.4.
-template <int DBG, int WS = -1, bool RAG = false, bool M16 = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
+// UB (round 3 experiment, instantiated in the tools library only; ap_capi.hip run_net under tools bit 0x400000): the GEMM1 operand
+// comes ready-made.  Beside h' (fp32, what the residual
+// and the next layer's residual need) the first epilogue writes ub' = bf16(h' + part_t of the NEXT layer) -- the value the next
+// layer's staging would compute, so the two forms are bit-identical -- as [clip][32-channel chunk][sample][32 channels]: a chunk's
+// (column, tap) operand is one 64-byte run, staged with a 16-byte load + ds_write_b128 per lane (three per thread and chunk for
+// every dilation and every clip length: no FiLM add / convert / mask in the loop, no alignment cases, 24.6 KB per chunk on the
+// CU's memory path instead of 64), out-of-clip taps read through an out-of-range offset (zeros).  A wave's first-pass rows are
+// exactly one chunk, so its ub' stores are contiguous 2 KB runs.  Layer 0's image comes from make_ub_kernel.  Result: eps of the
+// 36-layer sweep BIT-IDENTICAL to the layer-wise form (L = 16000, 4001, 1002, 643, 130), each launch +1 %, the sweep +3 %
+// (tools/ab_bf16_ub.py, profiles/r3_bf16_operand_images_experiment.txt): the block runs at the board's 1400 W power cap
+// (tools/power_check.py), and 64 KB of extra stores per tile cost more energy than 0.3 MB less on the L2 -> CU path and the
+// pack's VALU save.  (The "no X requests / no pack" ablations that promised 13-25 % leave the X image CONSTANT: what they measure
+// is the matrix pipe's data-dependent power, not the staging -- tools/power_ablate_bf16.py.)
+template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
     const void *__restrict__ bbase, unsigned bbytes, unsigned b1_off, unsigned b2_off,        // fp32 bias vectors (one slab)
-    int L, int d, int accumulate, int ntiles, int nblk) {
+    int L, int d, int accumulate, int ntiles, int nblk,
+    const void *__restrict__ ubin, void *__restrict__ ubout, const float *__restrict__ ptn) {   // UB: bf16 operand images in / out (out may be null), the next layer's part_t
   constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
+  static_assert(!UB || (WS < 0 && !M16), "UB: one staging form");
   // cache policy: nt (aux bit 1) on the once-touched streams (the running skip rows in, both outputs out) and on the residual's
   // re-read of h (it hits what is still there and allocates nothing on a miss).  Only the tap loads and the weights allocate in
   // the XCD's L2, so h rows stay until the neighbouring tiles' taps and the residual have read them again: L2-miss reads 27.2 ->
   // 19.4 GB per 512-clip launch (traffic 1.31 -> 1.08 x algorithmic), -3 % time.  DBG 0x4000: default policy everywhere.
   constexpr int NT = (DBG & 0x4000) ? 0 : 2;
+  // store policy experiments (tools): DBG 0x1000000 default, 0x2000000 sc0 + nt, 0x3000000 sc1 + nt, 0x5000000 sc1 (agent scope write-through)
+  constexpr int NTS = (DBG & 0x7000000) == 0x1000000 ? 0 : (DBG & 0x7000000) == 0x2000000 ? 3 : (DBG & 0x7000000) == 0x3000000 ? 18 : (DBG & 0x7000000) == 0x5000000 ? 16 : NT;
   constexpr bool WIN = WS >= 0;
   // M16 without the window: 224-byte rows and no swizzle -- with the 16 x 4 lane pattern of the 16x16x32 B fragment the 16-lane groups
   // of ds_read_b128 are conflict-free iff the row stride is 14 (or 2) slots of 16 B mod 16 (208 B = 13 slots is 2-way); the
   // pack's ds_write_b128 is 2-way there (16 LDS cycles against the 13 its register transfer takes: measured free in round 2).
   // The window variants keep 208-byte rows (their scratch column quad leaves no LDS for longer ones).
   constexpr int XS = (M16 && !WIN) ? 112 : XS_;
-  constexpr int SWZ = (M16 && !WIN) ? 0 : 1;
+  constexpr int SWZ = ((M16 && !WIN) || UB) ? 0 : 1;            // (UB: column pairs four apart per ds_write_b128 group -- conflict-free unswizzled)
   constexpr int XBYTES = (PT_ + (WIN ? 4 : 0)) * XS * 2;        // 26,624 B per X buffer (WIN: + a scratch column quad), two buffers
   constexpr int GOFF = 2 * XBYTES;
   constexpr int POFF = GOFF + PT_ * GS_ * 2;                   // output patches: 8 waves x 32 x 32 fp32
   constexpr int PTOFF = POFF + NW * 32 * PS_ * 4;              // part_t (C floats)
   constexpr int BOFF = PTOFF + C * 4;                          // b1 (2C floats: filter | gate rows), b2 (2C: res | skip rows)
-  constexpr int LDS_BYTES = BOFF + 4 * C * 4;
+  constexpr int PNOFF = BOFF + 4 * C * 4;                      // UB: the next layer's part_t (C floats)
+  constexpr int LDS_BYTES = PNOFF + (UB ? C * 4 : 0);
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
@@ -251,6 +298,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   //  reload in the chunk loop is a vector-memory load whose wait drains every request in flight)
 
   if (tid < C) reinterpret_cast<float *>(lds + PTOFF)[tid] = pt[tid];
+  if constexpr (UB) {
+    if (tid < C) reinterpret_cast<float *>(lds + PNOFF)[tid] = ubout ? ptn[tid] : 0.f;
+  }
   // the bias vectors live in LDS for the whole kernel: fetched per tile from memory they sat behind the previous tile's
   // stores in the in-order vmcnt queue, kept in registers they spilled
   {
@@ -305,8 +355,25 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     }
   };
   calc_xwb(sq, wc4);
+  // UB staging unit: thread = (column 16 wave + cw, channel octet ln & 3) for the three taps; cw pairs columns four apart inside
+  // an 8-lane ds_write_b128 group (832 B apart = 16 banks: conflict-free), a wave's load is 16 columns x 64 B = 1 KB contiguous
+  unsigned xv[UB ? 3 : 1];                                       // byte offsets of the three taps' rows inside the clip's image
+  u32x4 xq[UB ? 3 : 1];
+  auto ub_col = [&](int ln) { const int q = ln >> 2; return 16 * wave + (((q & 1) << 2) | ((q >> 1) & 3) | (q & 8)); };
   auto x_geom = [&](int t0_in, unsigned &voff, Keep &k) {
     const int t0 = (DBG & 1024) ? 8192 : t0_in;                  // timing-only: every tile stages the same 128 columns of clip 0
+    if constexpr (UB) {
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int col = ub_col(ln);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const int t = t0 + col + (i - 1) * d;
+        xv[i] = (t >= 0 && t < L) ? (unsigned)(t * 64 + (ln & 3) * 16) : 0x80000000u;     // outside the clip: zeros (WaveNet.py:26-27)
+      }
+      (void)voff; (void)k;
+      return;
+    }
     // the lane's geometry is re-derived from a lane id read here (volatile asm: not hoisted out of the tile loop): kept from
     // the prologue it was spilled, and a scratch reload waits with vmcnt(0) -- here, behind the first epilogue's stores
     int ln;
@@ -342,7 +409,12 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     for (int i = 0; i < 4; i++) xr[e * 4 + i] = v[i];
   };
   auto issue_x = [&](const __amdgpu_buffer_rsrc_t &rs_in, unsigned voff, int ch) {
-    if constexpr (WIN) {
+    if constexpr (UB) {                                          // rs_in: the clip's bf16 image; chunk ch = L x 64 bytes
+      if constexpr (DBG & 2) return;
+#pragma unroll
+      for (int i = 0; i < 3; i++) xq[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, xv[i], ch * L * 64, 0));
+      (void)voff;
+    } else if constexpr (WIN) {
       if (wave < 6) {                                            // wave-uniform
 #pragma unroll
         for (int e = 0; e < 4; e++) issue_x1(rs_in, voff, ch, e);
@@ -354,9 +426,15 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   };
   float ptv8[8];
   u32x4 pkq;
+  unsigned xwa = 0;                                             // UB: this thread's place in an X buffer (tap 0), re-derived per chunk
   auto pack_ptv = [&](int ch) {
     int ln;                                                     // (lane id read here, not kept: see x_geom)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    if constexpr (UB) {
+      xwa = (unsigned)((ub_col(ln) * XS + (ln & 3) * 8) * 2);
+      (void)ch;
+      return;
+    }
     if constexpr (M16) {                                        // the pack's LDS addresses live from here to the chunk's last piece only
       if constexpr (WIN) calc_xwb(min(wave, 5) * 8 + (ln >> 3), ln & 7);
       else {
@@ -382,6 +460,11 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   auto pack_piece = [&](unsigned char *dst, const Keep &keep, auto i_tag, auto hf_tag) {
     constexpr int i = decltype(i_tag)::value, hf = decltype(hf_tag)::value;
     if constexpr (DBG & 4) return;
+    if constexpr (UB) {                                          // pieces (0,0), (1,0), (2,0): tap i's 16 bytes straight into the image
+      if constexpr (hf == 0 && i < 3) *reinterpret_cast<u32x4 *>(dst + xwa + i * (KC_ * 2)) = xq[i];
+      (void)keep;
+      return;
+    }
     // RAG: keep.m[0] counts the quad's valid samples -> all ones for sample i iff i < count
     const unsigned km = RAG ? (unsigned)(((int)i - (int)keep.m[0]) >> 31) : keep.m[0];
     if constexpr (WIN) {
@@ -457,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   const int rd16e = (c16 * XS) * 2 + ((q4 ^ (SWZ * 2 * par16)) * 16);           // even ct16
   const int rd16o = (c16 * XS) * 2 + ((q4 ^ (SWZ * 2 * (par16 ^ 1))) * 16);     // odd ct16
   const int rdoff = (j * XS + 8 * hh) * 2;                      // this lane's B-fragment byte offset inside an X buffer
-  const int rdsw = (__builtin_popcount((j >> 2) & 7) & 1) * 32;
+  const int rdsw = SWZ * (__builtin_popcount((j >> 2) & 7) & 1) * 32;
   const unsigned char *gb = lds + GOFF + (j * GS_ + 8 * hh) * 2;
   float *patch = reinterpret_cast<float *>(lds + POFF) + wave * 32 * PS_;
   const float RS = 0.707106781186547524f;
@@ -466,6 +549,14 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   int b_cur, t0_cur;
   tile_bt(t_first, b_cur, t0_cur);
   __amdgpu_buffer_rsrc_t hrs = clip_rsrc(hin, b_cur);
+  auto ub_rsrc = [&](const void *base, int b) {                  // a clip's bf16 image: [C / 32][L][32]
+    const uint64_t hb = (uint64_t)base + (uint64_t)b * ((uint64_t)C * (uint64_t)L * 2u);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)(clip_bytes / 2u), 0x00020000);
+  };
+  __amdgpu_buffer_rsrc_t urs = UB ? ub_rsrc(ubin, b_cur) : hrs;
+#define AP_XRS (UB ? urs : hrs)
   unsigned xvoff;
   x_geom(t0_cur, xvoff, keep);
   // a tile's first X chunk and first weight fragments are requested at the END of the previous tile, ahead of that tile's
@@ -488,9 +579,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       for (int rt = 0; rt < 2; rt++) w[ks][rt] = ld_w1(ks * 2 + rt);
     }
     pack_all(lds, keep, 0);
-    issue_x(hrs, xvoff, 1);                                      // chunk 1: packed in chunk 0's fourth k-step
+    issue_x(AP_XRS, xvoff, 1);                                   // chunk 1: packed in chunk 0's fourth k-step
   };
-  issue_x(hrs, xvoff, 0);
+  issue_x(AP_XRS, xvoff, 0);
   __syncthreads();                                               // part_t, biases visible
   tile_head();
 
@@ -644,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           }
           if (ct == 3 && reload) w[ks % RING][1] = ld_w1(nfrag + 1);
           if constexpr (WITH_X) {
-            if (ks == 5 && ct == 3) issue_x(hrs, xvoff, ch + 2);
+            if (ks == 5 && ct == 3) issue_x(AP_XRS, xvoff, ch + 2);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -700,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
               else if (s2 < 2) rdb16(bv[ct & 3], ct - 4, s2 + 1);
             }
             if constexpr (WITH_X) {
-              if (s2 == 2 && ct == 7 && rt == 3) issue_x(hrs, xvoff, ch + 2);
+              if (s2 == 2 && ct == 7 && rt == 3) issue_x(AP_XRS, xvoff, ch + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -897,8 +988,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     };
     // epilogue of a pass: MFMA layout (4 rows x 1 column per lane) -> wave-private LDS patch -> 1 row x 4 columns per lane,
     // so the stores (like the operand loads) are 16 B per lane
+    const __amdgpu_buffer_rsrc_t uors = UB ? ub_rsrc(ubout, b_cur) : hrs;
     auto epilogue = [&](const f32x16(&ac)[4], const float(&add)[4][16], const __amdgpu_buffer_rsrc_t &dst, float scale,
                         auto first_tag) {
+      constexpr bool UBW = UB && decltype(first_tag)::value;     // pass 0 of the chain's form also writes the next layer's operand image
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) {
         if constexpr (decltype(first_tag)::value) {             // pass 0: the h-patch registers of tiles 0, 1 are free again
@@ -922,13 +1015,40 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
             const int nv = L - (t0 + 32 * ct + 4 * (lane & 7));  // valid samples of this lane's column quad (>= 4: all)
             const unsigned so = evoff[ct] + (unsigned)(8 * p * L * 4);
             const u32x4 ou = __builtin_bit_cast(u32x4, o);       // (whole-vector bit_cast: element-wise it is mis-folded to a splat)
-            if (nv >= 4) __builtin_amdgcn_raw_buffer_store_b128(ou, dst, so, 0, NT);
+            if (nv >= 4) __builtin_amdgcn_raw_buffer_store_b128(ou, dst, so, 0, NTS);
             else {
               if (nv >= 1) __builtin_amdgcn_raw_buffer_store_b32(ou[0], dst, so, 0, NT);
               if (nv >= 2) __builtin_amdgcn_raw_buffer_store_b32(ou[1], dst, so + 4u, 0, NT);
               if (nv >= 3) __builtin_amdgcn_raw_buffer_store_b32(ou[2], dst, so + 8u, 0, NT);
             }
-          } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst, evoff[ct] + (unsigned)(8 * p * L * 4), 0, NT);
+          } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), dst, evoff[ct] + (unsigned)(8 * p * L * 4), 0, NTS);
+          if constexpr (UBW) {                                  // h' + part_t(next layer) back into the patch, in place
+#pragma clang fp contract(off)                                  // the sum of the ROUNDED h' and part_t, as the next layer's staging forms it: (add + v) * scale + pn as one fma
+                                                                // is a different number (seen: the non-ragged instantiation contracted it, the ragged one did not)
+            const float pn = reinterpret_cast<const float *>(lds + PNOFF)[32 * wave + (lane >> 3) + 8 * p];
+            *reinterpret_cast<float4 *>(patch + ((lane >> 3) + 8 * p) * PS_ + 4 * (lane & 7)) = make_float4(o[0] + pn, o[1] + pn, o[2] + pn, o[3] + pn);
+          }
+        }
+        if constexpr (UBW) {
+          // column j of the patch, channels 16 hh .. 16 hh + 15 -> 32 bytes of ub'[clip][chunk = wave][t0 + 32 ct + j][.]
+          asm volatile("" ::: "memory");                          // (the patch is written and read through different types: keep the order)
+          if (ubout) {                                           // (uniform; null on the net's last layer)
+            u32x4 lo4, hi4;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+              const f32x2 v2 = {patch[(16 * hh + 2 * e) * PS_ + j], patch[(16 * hh + 2 * e + 1) * PS_ + j]};
+              const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
+              if (e < 4) lo4[e] = pk; else hi4[e - 4] = pk;
+            }
+            const int t = t0 + 32 * ct + j;
+            // (chunk step in the VGPR offset, soffset = 0: see the note on buffer stores above)
+            const unsigned uo = t < L ? (unsigned)((wave * L + t) * 64 + hh * 32) : 0x80000000u;
+            if constexpr (!(DBG & 256)) {
+              __builtin_amdgcn_raw_buffer_store_b128(lo4, uors, uo, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(hi4, uors, uo + 16u, 0, 0);
+            }
+          }
+          asm volatile("" ::: "memory");
         }
       }
     };
@@ -950,8 +1070,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     // (unconditional from here: after its last tile a workgroup re-requests that tile's first chunk and drops it -- a
     // conditional request would keep the staging and fragment registers live across the whole tile)
     hrs = clip_rsrc(hin, b_nxt);
+    if constexpr (UB) urs = ub_rsrc(ubin, b_nxt);
     x_geom(t0_nxt, xvoff, keep);
-    issue_x(hrs, xvoff, 0);
+    issue_x(AP_XRS, xvoff, 0);
     __builtin_amdgcn_sched_barrier(0);
     {
       f32x16 ac[4];
@@ -982,7 +1103,7 @@ namespace ap {
 
 // -> 0 launched, 1 shape not served by this kernel (caller falls back to the per-tile kernel)
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                          int B, int L, hipStream_t st) {
+                          int B, int L, hipStream_t st, const UbArgs *ub) {
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   if (C != 256 || S != 256 || L < 1) return 1;
@@ -1014,14 +1135,25 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   const unsigned bbytes = (unsigned)((bhi - blo + (size_t)ctx->NL * 2 * C) * 4);
 #define AP_P_LAUNCH(D)                                                                                                        \
   resblock_bf16p_kernel<D><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, \
-                                                           b2_off, L, d, accumulate, ntiles, nblk)
+                                                           b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr)
 #define AP_P_LAUNCH_WIN(D, W)                                                                                                 \
   resblock_bf16p_kernel<D, W><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,  \
-                                                              b1_off, b2_off, L, d, accumulate, ntiles, nblk)
+                                                              b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr)
 #define AP_P_LAUNCH_RAG(W)                                                                                                    \
   resblock_bf16p_kernel<0, W, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, \
-                                                                    b1_off, b2_off, L, d, accumulate, ntiles, nblk)
+                                                                    b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr)
 #ifdef AP_TOOLS
+  if (ub) {                                                      // the operand-image experiment: images in / out, one staging form for every d
+    if ((size_t)C * (size_t)L * 2 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16: clip too long for the bf16 operand image"); return -22; }
+    if (rag)
+      resblock_bf16p_kernel<0, -1, true, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,
+                                                                                      b1_off, b2_off, L, d, accumulate, ntiles, nblk, ub->in, ub->out, ub->pt_next);
+    else
+      resblock_bf16p_kernel<0, -1, false, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,
+                                                                                       b1_off, b2_off, L, d, accumulate, ntiles, nblk, ub->in, ub->out, ub->pt_next);
+    AP_HIP(hipGetLastError());
+    return 0;
+  }
   if (rag) {
     if (ws == 1) AP_P_LAUNCH_RAG(1);
     else if (ws == 2) AP_P_LAUNCH_RAG(2);
@@ -1037,9 +1169,13 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   if ((g_dbg_bf16 & 0x200000) && ctx->w1q_bf) {                  // tools bit 0x200000: GEMM1 on v_mfma_f32_16x16x32_bf16 (exact; A/B)
     const unsigned w1q_off = (unsigned)((const char *)ctx->w1q_bf - wlo + layer * n1 * 2);
     resblock_bf16p_kernel<0, -1, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1q_off, w2_off, blo,
-                                                                            bbytes, b1_off, b2_off, L, d, accumulate, ntiles, nblk);
+                                                                            bbytes, b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr);
   } else
   if (g_dbg_bf16 & 0x100000) AP_P_LAUNCH(0x100000);             // timing only: v_mfma_f32_16x16x32_bf16 pairs in place of 32x32x16
+  else if ((g_dbg_bf16 & 0x7000000) == 0x1000000) AP_P_LAUNCH(0x1000000);   // store cache policies (exact)
+  else if ((g_dbg_bf16 & 0x7000000) == 0x2000000) AP_P_LAUNCH(0x2000000);
+  else if ((g_dbg_bf16 & 0x7000000) == 0x3000000) AP_P_LAUNCH(0x3000000);
+  else if ((g_dbg_bf16 & 0x7000000) == 0x5000000) AP_P_LAUNCH(0x5000000);
   else
   switch (g_dbg_bf16 & 0xefff) {
     case 0: AP_P_LAUNCH(0); break;
@@ -1104,12 +1240,12 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 // (C = S = 256; any dilation of a power-of-two cycle, any clip length).  The one-tile-per-workgroup kernel of round 1
 // (ap_resblock_bf16.hip) is compiled into the tools library only, as the A/B baseline of tools/cmp_bf16_kernels.py.
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                         int B, int L, hipStream_t st) {
+                         int B, int L, hipStream_t st, const UbArgs *ub) {
   if (ctx->C != 256 || ctx->S != 256) {
     set_error("AP_PREC_BF16 is built for res_channels = skip_channels = 256 only (got %d / %d)", ctx->C, ctx->S);
     return -22;
   }
-  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub);
   if (rc == 1) {
     set_error("AP_PREC_BF16: shape not served (layer %d, L = %d)", layer, L);
     return -22;
