@@ -6,7 +6,7 @@
 #      GRBM_GUI_ACTIVE) of the SAME command, split per layer by dispatch order;
 #   3. tools-build evidence of the bf16 block: phase stamps, ablations, bit identity of the persistent kernel with the round-1
 #      kernel (aligned and ragged lengths), the one-wave-per-SIMD experiment;
-#   4. configs[4]: per conv shape.
+#   4. configs[4]: per conv shape, and the rocprofv3 --stats split of the whole step;
 #   bash tools/profile_round3.sh [outdir under gpurun_out]        then: python tools/summarize_round3.py <outdir>
 set -u
 out=${1:-gpurun_out/r3}
@@ -28,4 +28,11 @@ timeout 600 python3 "$repo/tools/dbg_resblock_bf16.py" 256 0 4096 1 2 3 4 8 128 
 { timeout 300 python3 "$repo/tools/cmp_bf16_kernels.py" 4; for L in 130 1001 1002 1003 23457; do echo "L = $L"; AP_CMP_L=$L timeout 300 python3 "$repo/tools/cmp_bf16_kernels.py" 2 0 1 3 5 9 11; done; } > "$repo/$out/cmp_kernels.txt" 2>&1
 { timeout 300 python3 "$repo/tools/ab_bf16w.py" 256 3 2 5 9 11; timeout 300 python3 "$repo/tools/trace_resblock_bf16w.py" 256 9; timeout 300 python3 "$repo/tools/ablate_bf16w.py" 256 9 2; } > "$repo/$out/bf16w_experiment.txt" 2>&1
 timeout 600 python3 "$repo/tools/conv_by_shape.py" 256 > "$repo/$out/cfg4_conv_by_shape.txt" 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/cfg4_stats" -o r -- python3 "$repo/tools/run_cfg4_step.py" 256 3 > "$repo/$out/cfg4_step.log" 2>&1
+cp "$repo/$out"/cfg4_stats/*kernel_stats.csv "$repo/$out/cfg4_kernel_stats.csv" 2>/dev/null
+#   5. power: board power / shader clock per block kernel (random and all-zero activations), the energy table of the bf16 block's
+#      ablations, the conv kernels, the operand-image experiment
+{ timeout 300 python3 "$repo/tools/power_check.py" 5 256; AP_ZERO=1 timeout 300 python3 "$repo/tools/power_check.py" 4 256; timeout 200 python3 "$repo/tools/power_check_conv.py" 4; } 2>&1 | grep -v amdgpu.ids > "$repo/$out/power_by_mode.txt"
+timeout 400 python3 "$repo/tools/power_ablate_bf16.py" 256 3 2>&1 | grep -v amdgpu.ids > "$repo/$out/bf16_energy_ablation.txt"
+timeout 400 python3 "$repo/tools/ab_bf16_ub.py" 256 2 2>&1 | grep -v amdgpu.ids > "$repo/$out/bf16_operand_images_experiment.txt"
 ls "$repo/$out"

@@ -116,3 +116,8 @@ text("ablation.txt", "r3_bf16_ablation_persistent.txt")
 text("cmp_kernels.txt", "r3_bf16_persistent_vs_pertile.txt")
 text("bf16w_experiment.txt", "r3_bf16w_one_wave_per_simd_experiment.txt")
 text("cfg4_conv_by_shape.txt", "r3_cfg4_conv_by_shape.txt")
+text("power_by_mode.txt", "r3_power_by_mode.txt")
+text("bf16_energy_ablation.txt", "r3_bf16_energy_ablation.txt")
+text("bf16_operand_images_experiment.txt", "r3_bf16_operand_images_experiment.txt")
+if os.path.exists(os.path.join(src, "cfg4_kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "cfg4_kernel_stats.csv"), os.path.join(P, "r3_cfg4_kernel_stats.csv"))
