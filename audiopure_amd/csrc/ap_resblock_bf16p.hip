@@ -1185,6 +1185,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     case 4: AP_P_LAUNCH(4); break;
     case 7: AP_P_LAUNCH(7); break;
     case 8: AP_P_LAUNCH(8); break;
+    case 16: AP_P_LAUNCH(16); break;
     case 23: AP_P_LAUNCH(23); break;
     case 31: AP_P_LAUNCH(31); break;
     case 31 + 128: AP_P_LAUNCH(31 + 128); break;

@@ -29,7 +29,7 @@ constexpr int BT = 128;                  // time tile
 constexpr int BKC = 16;                  // channels per staged chunk -> 48 K rows = 3 k-steps (one per tap)
 constexpr int XS = 3 * BKC + 8;          // bf16 per column row of an X image (112 B: conflict-free b128 reads)
 constexpr int HT = 64;                   // columns per gate/GEMM2 half
-constexpr int PSTR = 36;                 // fp32 row stride of the wave-private output patch
+constexpr int PSTR = 32;                 // fp32 row stride of the wave-private output patch (128-B rows: conflict-free for the column writes and the 16-lane groups of the b128 row reads; 144-B rows were 2-way)
 
 __device__ __forceinline__ int rowoff_s(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 

@@ -8,7 +8,7 @@ from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNe
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
-variants = [int(a, 0) for a in sys.argv[3:]] or [0, 1024, 1, 2, 4, 8, 32, 64, 96, 128, 256, 384, 31, 384 + 31 + 96]
+variants = [int(a, 0) for a in sys.argv[3:]] or [0, 1024, 1, 2, 4, 8, 16, 32, 64, 96, 128, 256, 384, 31, 384 + 31 + 96]
 NAMES = {0: "product kernel", 0x1000000: "stores: default policy (exact)", 0x2000000: "stores: sc0 + nt (exact)", 0x3000000: "stores: sc1 + nt (exact)", 0x5000000: "stores: sc1 (exact)", 0x4000: "default policy everywhere (exact)", 1024: "X from cache-resident lines (no HBM reads of h)", 96: "no gate math, no GEMM2 MFMA", 1: "no weight requests (GEMM1)", 2: "no X requests", 4: "no pack", 8: "no GEMM1 MFMA", 16: "no B-fragment LDS reads",
          32: "no gate math", 64: "no GEMM2 MFMA", 128: "no read-modify-write loads", 256: "no stores", 384: "no RMW loads, no stores",
          31: "GEMM1 emptied (1+2+4+8+16)", 384 + 31 + 96: "everything off but the loop"}
