@@ -829,14 +829,17 @@ using namespace ap;
 #ifdef AP_TOOLS
 static int g_conv_no_frag = 0;     // ap_debug_conv_path(1): timing A/B against the LDS-staged 128 x 128 kernel
 static long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
+static int g_conv_wide_1x1 = 0;               // ap_debug_conv_path(2): pointwise layers on 128 x 128 tiles again (A/B)
 extern "C" int ap_debug_conv_path(int no_frag) {
   if (no_frag >= 16) g_conv_frag_min_tiles = no_frag;   // >= 16: set the tile-count threshold of the streamed-weight kernel
+  else if (no_frag == 2 || no_frag == 3) g_conv_wide_1x1 = no_frag == 2;   // 2 / 3: pointwise layers on 128 x 128 tiles / back on 128 x 64
   else g_conv_no_frag = no_frag;
   return 0;
 }
 #else
 static constexpr int g_conv_no_frag = 0;
 static constexpr long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
+static constexpr int g_conv_wide_1x1 = 0;
 #endif
 
 // layers the streamed-weight kernel serves carry a second image behind the first
@@ -1044,7 +1047,7 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
       *cls = 1;
       if (buf) conv2d_f32_big2_kernel<64, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else conv2d_f32_big2_kernel<64, 128, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
-    } else if (tiles128 >= g_conv_frag_min_tiles) {
+    } else if (tiles128 >= g_conv_frag_min_tiles && !(kh == 1 && kw == 1 && !g_conv_wide_1x1)) {   // (pointwise layers: 128 x 64 below)
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 127) / 128), (unsigned)groups);
       *cls = 0;
       if (buf && p1) conv2d_f32_big2_kernel<128, 128, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
