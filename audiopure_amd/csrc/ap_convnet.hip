@@ -830,8 +830,10 @@ using namespace ap;
 static int g_conv_no_frag = 0;     // ap_debug_conv_path(1): timing A/B against the LDS-staged 128 x 128 kernel
 static long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
 static int g_conv_wide_1x1 = 0;               // ap_debug_conv_path(2): pointwise layers on 128 x 128 tiles again (A/B)
+static int g_conv_force = 0;                  // ap_debug_conv_path(4..7): every streamed-weight layer on 128x128 / 128x64 / 64x64 / 64x128 tiles; 8: off
 extern "C" int ap_debug_conv_path(int no_frag) {
   if (no_frag >= 16) g_conv_frag_min_tiles = no_frag;   // >= 16: set the tile-count threshold of the streamed-weight kernel
+  else if (no_frag >= 4 && no_frag <= 8) g_conv_force = no_frag == 8 ? 0 : no_frag;
   else if (no_frag == 2 || no_frag == 3) g_conv_wide_1x1 = no_frag == 2;   // 2 / 3: pointwise layers on 128 x 128 tiles / back on 128 x 64
   else g_conv_no_frag = no_frag;
   return 0;
@@ -1042,6 +1044,22 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
         *cls = 3;
         conv2d_split_kernel<128, 128><<<grid, 256, 0, (hipStream_t)stream>>>(a, sfrag);
       }
+#ifdef AP_TOOLS
+    } else if (g_conv_force && buf && groups == 1) {                   // tools: one tile shape for every layer (sweeps)
+      const int fm = (g_conv_force == 4 || g_conv_force == 5) ? 128 : 64, fn = (g_conv_force == 4 || g_conv_force == 7) ? 128 : 64;
+      dim3 grid((unsigned)((N + fn - 1) / fn), (unsigned)((Mg + fm - 1) / fm), 1u);
+      *cls = 2;
+#define AP_FORCE(BM_, BN_)                                                                                                          \
+  do {                                                                                                                              \
+    if (p1) conv2d_f32_big2_kernel<BM_, BN_, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes); \
+    else conv2d_f32_big2_kernel<BM_, BN_, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);          \
+  } while (0)
+      if (g_conv_force == 4) AP_FORCE(128, 128);
+      else if (g_conv_force == 5) AP_FORCE(128, 64);
+      else if (g_conv_force == 6) AP_FORCE(64, 64);
+      else AP_FORCE(64, 128);
+#undef AP_FORCE
+#endif
     } else if (Mg < 128) {                                             // 64 <= Cout/g < 128
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Mg + 63) / 64), (unsigned)groups);
       *cls = 1;
