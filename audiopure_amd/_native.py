@@ -95,6 +95,7 @@ SIGNATURES = {
     "ap_conv2d_packed_elems": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "ap_conv2d_pack": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "ap_conv2d_fwd": (_i, [_fp, _fp, _fp, _fp, _fp] + [_i] * 13 + [_vp]),
+    "ap_conv2d_fwd_slice": (_i, [_fp, _fp, _fp, _fp, _fp] + [_i] * 15 + [_vp]),
     "ap_affine_nchw": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _vp]),
     "ap_add_nchw": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ap_copy_channels": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -21,6 +21,8 @@ struct ConvArgs {
   int x_coff;        // first channel of the slice
   int splits;        // > 1: split-K (groups == 1): blockIdx.z = slice of the chunk range, raw partial sums go to `part`
   float *part;       // [splits][B][Cout][Ho][Wo]
+  int o_cstride;     // channels of the tensor `out` lives in (ap_conv2d_fwd_slice: out is a channel slice; Cout otherwise)
+  int o_coff;        // first channel of that slice (streamed-weight kernel and its split-K reduce only)
 };
 
 __device__ __forceinline__ int crowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
               if (a.bias) v += a.bias[co];
               if (a.res) v += a.res[off];
               if (a.relu) v = fmaxf(v, 0.f);
-              a.out[off] = v;
+              a.out[((size_t)ob * a.o_cstride + a.o_coff + co) * HoWo + op] = v;
             }
           }
         }
@@ -468,7 +470,8 @@ __global__ void conv_splitk_reduce_kernel(ConvArgs a, size_t total) {
     if (a.bias) r += a.bias[(off / HoWo) % a.Cout];
     if (a.res) r += a.res[off];
     if (a.relu) r = fmaxf(r, 0.f);
-    a.out[off] = r;
+    const size_t per = (size_t)a.Cout * HoWo, ob = off / per;
+    a.out[(ob * a.o_cstride + a.o_coff) * HoWo + (off - ob * per)] = r;
   }
 }
 
@@ -903,7 +906,7 @@ struct ConvProf {
 } g_cprof;
 int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin, int H,
                     int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride, int x_coff,
-                    void *stream, int *cls);
+                    void *stream, int *cls, int o_cstride = 0, int o_coff = 0);
 }  // namespace
 
 // Split-K partial sums live in a caller-owned device buffer (no allocation inside the library): without one, or with one
@@ -955,12 +958,13 @@ extern "C" int ap_conv_profile_read(double *ms_by_class, double *flop_by_class, 
   return 0;
 }
 
-extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias, const float *res, float *out, int B,
-                             int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
-                             int x_cstride, int x_coff, void *stream) {
+static int conv2d_fwd_entry(const float *x, const float *wT, const float *bias, const float *res, float *out, int B,
+                            int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
+                            int x_cstride, int x_coff, void *stream, int o_cstride, int o_coff) {
   int cls = 5;
   if (!g_cprof.on)
-    return conv2d_fwd_impl(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, &cls);
+    return conv2d_fwd_impl(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, &cls,
+                           o_cstride, o_coff);
   if (g_cprof.used + 2 > g_cprof.ev.size())
     for (int i = 0; i < 2; i++) {
       hipEvent_t e;
@@ -968,7 +972,8 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
       g_cprof.ev.push_back(e);
     }
   AP_HIP(hipEventRecord(g_cprof.ev[g_cprof.used], (hipStream_t)stream));
-  const int rc = conv2d_fwd_impl(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, &cls);
+  const int rc = conv2d_fwd_impl(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, &cls,
+                                 o_cstride, o_coff);
   AP_HIP(hipEventRecord(g_cprof.ev[g_cprof.used + 1], (hipStream_t)stream));
   if (rc) return rc;
   const bool one_d = (relu >> 9) & 1;
@@ -982,10 +987,26 @@ extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias,
   return 0;
 }
 
+// the same convolution with `out` a channel slice [out_coff, out_coff + Cout) of a tensor of out_cstride channels (torch.cat's
+// destination: the producer writes its half in place).  Served by the streamed-weight fp32 kernel (and its split-K reduce) only.
+extern "C" int ap_conv2d_fwd_slice(const float *x, const float *wT, const float *bias, const float *res, float *out, int B,
+                                   int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
+                                   int x_cstride, int x_coff, int out_cstride, int out_coff, void *stream) {
+  if (out_cstride < out_coff + Cout || out_coff < 0) { set_error("ap_conv2d_fwd_slice: bad output slice"); return -22; }
+  return conv2d_fwd_entry(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, out_cstride,
+                          out_coff);
+}
+
+extern "C" int ap_conv2d_fwd(const float *x, const float *wT, const float *bias, const float *res, float *out, int B,
+                             int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu,
+                             int x_cstride, int x_coff, void *stream) {
+  return conv2d_fwd_entry(x, wT, bias, res, out, B, Cin, H, W, Cout, kh, kw, stride, pad, groups, relu, x_cstride, x_coff, stream, 0, 0);
+}
+
 namespace {
 int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin, int H,
                     int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride, int x_coff,
-                    void *stream, int *cls) {
+                    void *stream, int *cls, int o_cstride, int o_coff) {
   if (!x || !wT || !out || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || stride < 1 || pad < 0 ||
       groups < 1 || Cin % groups || Cout % groups || x_cstride < x_coff + Cin) {
     set_error("ap_conv2d_fwd: bad argument");
@@ -1001,6 +1022,8 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
   relu &= 1;
   a.groups = groups; a.relu = relu; a.x_cstride = x_cstride; a.x_coff = x_coff;
   a.splits = 1; a.part = nullptr;
+  a.o_cstride = o_cstride ? o_cstride : Cout; a.o_coff = o_cstride ? o_coff : 0;
+  const bool sliced = a.o_cstride != Cout || a.o_coff != 0;
   a.dil_w = dil;
   a.dil_h = one_d ? 1 : dil;
   a.pad_h = one_d ? 0 : pad;
@@ -1012,6 +1035,10 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
   // the 128 x 128 tile needs enough workgroups to fill 256 CUs; otherwise 4x as many 64 x 64 tiles win
   const long long tiles128 = ((N + 127) / 128) * ((Mg + 127) / 128) * (long long)groups;
   const bool many = tiles128 >= 512;
+  if (sliced && !(conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag && !split && !splith)) {
+    set_error("ap_conv2d_fwd_slice: this layer is not served by the streamed-weight fp32 kernel (Cin/g %% 16, Cout/g >= 64, no split-operand flag)");
+    return -22;
+  }
   if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
     const size_t n1 = (size_t)Cout * (Cin / groups) * kh * kw;
     const float *afrag = wT + ((n1 + 3) & ~(size_t)3);

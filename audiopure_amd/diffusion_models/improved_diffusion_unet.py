@@ -156,9 +156,16 @@ class UNetModel(nn.Module):
         self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100, "f32h": 0x400}[mode]
         return self
 
-    def _conv(self, m, x, B, Cin, H, W, res=None, track=True):
+    def _conv(self, m, x, B, Cin, H, W, res=None, track=True, dest=None):
         wT, bias, cout, kh, kw, stride, pad = self._packed[m]
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        if dest is not None and Cin % 16 == 0 and cout >= 64 and getattr(self, "_conv_flags", 0) == 0 and self._tape is None:
+            # the layer's output is the first half of the next torch.cat (unet.py:490-491): written in place (ap_conv2d_fwd_slice)
+            cat = dest
+            assert cat.shape[0] == B and cat.shape[1] >= cout and tuple(cat.shape[2:]) == (Ho, Wo)
+            N.check(N.lib().ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), N.ptr(bias), N.ptr(res), N.ptr(cat), B, Cin, H, W, cout, kh, kw,
+                                                stride, pad, 1, 0, Cin, 0, cat.shape[1], 0, N.stream()), "ap_conv2d_fwd_slice")
+            return cat[:, :cout]
         out = torch.empty((B, cout, Ho, Wo), device=x.device, dtype=torch.float32)
         N.check(N.lib().ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, H, W, cout, kh, kw, stride,
                                       pad, 1, getattr(self, "_conv_flags", 0), Cin, 0, N.stream()), "ap_conv2d_fwd")
@@ -175,7 +182,7 @@ class UNetModel(nn.Module):
             self._tape.append(("gn", gn, x, ss, act, y))
         return y
 
-    def _resblock(self, rb, x, emb_proj):
+    def _resblock(self, rb, x, emb_proj, dest=None):
         B, C_, H, W = x.shape
         h = self._conv(rb.in_layers[2], self._gn(rb.in_layers[0], x), B, C_, H, W)                 # unet.py:181
         off, n = self._emb_rows[rb]                                                                 # :182: this block's rows of the
@@ -183,24 +190,44 @@ class UNetModel(nn.Module):
         N.check(N.lib().ap_copy_channels(N.ptr(emb_proj), N.ptr(ss), B, n, 1, emb_proj.shape[1], off, n, 0, N.stream()))
         h = self._gn(rb.out_layers[0], h, ss=ss)                                                   # :186-190 (+ SiLU)
         skip = x if isinstance(rb.skip_connection, nn.Identity) else self._conv(rb.skip_connection, x, B, C_, H, W)
-        return self._conv(rb.out_layers[3], h, B, rb.out_channels, H, W, res=skip)                 # :194
+        return self._conv(rb.out_layers[3], h, B, rb.out_channels, H, W, res=skip, dest=dest)      # :194
 
-    def _attention(self, ab, x):
+    def _attention(self, ab, x, dest=None):
         B, C_, H, W = x.shape
         qkv = self._conv(ab.qkv, self._gn(ab.norm, x, act=0), B, C_, H, W)                         # unet.py:229-230
         att = torch.empty_like(x)
         N.check(N.lib().ap_attention_qkv(N.ptr(qkv), N.ptr(att), B, C_, H * W, ab.num_heads, N.stream()), "ap_attention_qkv")
         if self._tape is not None:
             self._tape.append(("attn", qkv, att, ab.num_heads))
-        return self._conv(ab.proj_out, att, B, C_, H, W, res=x)                                    # :234-235
+        return self._conv(ab.proj_out, att, B, C_, H, W, res=x, dest=dest)                         # :234-235
 
-    def _run(self, seq, h, emb_proj):
+    def _out_shape(self, seq, C_, H, W):
+        """(channels, H, W) of a block's output, from its layers (to allocate the concatenation buffer its last layer writes into)."""
         for layer in seq:
-            B, C_, H, W = h.shape
             if isinstance(layer, ResBlock):
-                h = self._resblock(layer, h, emb_proj)
+                C_ = layer.out_channels
+            elif isinstance(layer, Downsample):
+                H, W = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+            elif isinstance(layer, Upsample):
+                H, W = 2 * H, 2 * W
+            elif isinstance(layer, nn.Conv2d):
+                _, _, C_, kh, kw, stride, pad = self._packed[layer]
+                H, W = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        return C_, H, W
+
+    def _run(self, seq, h, emb_proj, dest=None):
+        n = len(seq)
+        for i, layer in enumerate(seq):
+            B, C_, H, W = h.shape
+            d = dest if i == n - 1 else None                    # only a block's last layer writes into the next concatenation
+            if isinstance(layer, ResBlock):
+                h = self._resblock(layer, h, emb_proj, dest=d)
             elif isinstance(layer, AttentionBlock):
-                h = self._attention(layer, h)
+                h = self._attention(layer, h, dest=d)
+            elif isinstance(layer, Upsample) and d is not None:
+                up = torch.empty((B, C_, 2 * H, 2 * W), device=h.device, dtype=torch.float32)
+                N.check(N.lib().ap_upsample_nearest2x(N.ptr(h), N.ptr(up), B * C_, H, W, N.stream()), "ap_upsample_nearest2x")
+                h = self._conv(layer.conv, up, B, C_, 2 * H, 2 * W, dest=d)
             elif isinstance(layer, Downsample):
                 h = self._conv(layer.op, h, B, C_, H, W)
             elif isinstance(layer, Upsample):
@@ -259,17 +286,35 @@ class UNetModel(nn.Module):
         for blk in self.input_blocks:                                       # :486-488
             h = self._run(blk, h, emb_proj)
             hs.append(h)
-        h = self._run(self.middle_block, h, emb_proj)
-        for blk in self.output_blocks:                                      # :490-492
+        # h = th.cat([h, hs.pop()], dim=1) (:490-491): the block that produces h writes it straight into the concatenation's
+        # buffer (inference, fp32 arithmetic: ap_conv2d_fwd_slice); the skip half is copied; otherwise both halves are
+        direct = self._tape is None and getattr(self, "_conv_flags", 0) == 0
+
+        def next_cat(seq, hin):
+            if not direct or not hs:
+                return None
+            C1, H1, W1 = self._out_shape(seq, *hin.shape[1:])
+            skip = hs[-1]
+            if tuple(skip.shape[2:]) != (H1, W1):
+                return None
+            return torch.empty((B, C1 + skip.shape[1], H1, W1), device=dev, dtype=torch.float32)
+        cat = next_cat(self.middle_block, h)
+        h = self._run(self.middle_block, h, emb_proj, dest=cat)
+        for i, blk in enumerate(self.output_blocks):                        # :490-492
             skip = hs.pop()
             Bc, C1, H, W = h.shape
             C2 = skip.shape[1]
-            cat = torch.empty((Bc, C1 + C2, H, W), device=dev, dtype=torch.float32)
-            N.check(lib.ap_copy_channels(N.ptr(h), N.ptr(cat), Bc, C1, H * W, C1, 0, C1 + C2, 0, N.stream()))
+            if cat is not None and h.data_ptr() == cat.data_ptr() and not h.is_contiguous():     # h already sits in cat[:, :C1]
+                assert cat.shape[1] == C1 + C2
+            else:
+                cat = torch.empty((Bc, C1 + C2, H, W), device=dev, dtype=torch.float32)
+                N.check(lib.ap_copy_channels(N.ptr(h), N.ptr(cat), Bc, C1, H * W, C1, 0, C1 + C2, 0, N.stream()))
             N.check(lib.ap_copy_channels(N.ptr(skip), N.ptr(cat), Bc, C2, H * W, C2, 0, C1 + C2, C1, N.stream()))
             if self._tape is not None:
                 self._tape.append(("cat", h, skip, cat))
-            h = self._run(blk, cat, emb_proj)
+            ncat = next_cat(blk, cat) if i + 1 < len(self.output_blocks) else None
+            h = self._run(blk, cat, emb_proj, dest=ncat)
+            cat = ncat
         Bc, C_, H, W = h.shape
         return self._conv(self.out[2], self._gn(self.out[0], h), Bc, C_, H, W)                     # :494
 

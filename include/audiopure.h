@@ -267,6 +267,13 @@ int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int 
 int ap_conv2d_fwd(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin,
                   int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride,
                   int x_coff, void *stream);
+/* ap_conv2d_fwd with `out` a channel slice [out_coff, out_coff + Cout) of a tensor of out_cstride channels -- the destination
+ * of the torch.cat that follows the layer in improved_diffusion/unet.py:490-491 (h = th.cat([h, hs.pop()], dim=1)): the layer
+ * that produces h writes it in place.  `res` keeps the shape of the convolution's own output.  Layers of the streamed-weight
+ * fp32 kernel only (Cin/g % 16 == 0, Cout/g >= 64, no split-operand flag); -22 otherwise. */
+int ap_conv2d_fwd_slice(const float *x, const float *wT, const float *bias, const float *res, float *out, int B, int Cin,
+                        int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups, int relu, int x_cstride,
+                        int x_coff, int out_cstride, int out_coff, void *stream);
 /* y[B][C][HW] = [relu](x * scale[c] + shift[c]); scale == NULL: plain (optionally ReLU'd) copy of the slice. */
 int ap_affine_nchw(const float *x, const float *scale, const float *shift, float *y, int B, int C, int HW,
                    int x_cstride, int x_coff, int relu, void *stream);

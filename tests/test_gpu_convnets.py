@@ -150,3 +150,39 @@ def test_split_k_and_few_output_paths_match_torch_and_are_deterministic(dev):
         got = conv(x, w, b, None, 1, True)
         assert rel_err(got.cpu().numpy(), torch.nn.functional.conv2d(x, w, b, padding=1).cpu().numpy()) < 5e-6
     N.use_conv_workspace(dev)
+
+
+def test_conv_output_written_as_a_channel_slice_is_bit_identical_and_touches_nothing_else(dev):
+    """ap_conv2d_fwd_slice (the producer of h in `h = th.cat([h, hs.pop()], dim=1)`, improved_diffusion/unet.py:490-491, writes
+    its half of the concatenation in place): the slice equals ap_conv2d_fwd's output bit for bit on the main 128 x 128 kernel, the
+    pointwise 128 x 64 form and the split-K path (reduce kernel), the rest of the wider tensor is untouched; layers the
+    streamed-weight kernel does not serve are refused."""
+    from audiopure_amd import _native as N
+    lib = N.lib()
+    torch.manual_seed(5)
+    N.use_conv_workspace(dev)
+    for (B, Cin, H, W, Cout, k, extra, coff) in ((16, 128, 32, 32, 128, 3, 64, 0), (16, 256, 16, 16, 256, 1, 128, 0), (64, 256, 4, 4, 256, 3, 256, 0),
+                                                (8, 64, 16, 16, 192, 3, 32, 16), (3, 32, 9, 7, 64, 1, 8, 8)):
+        x = torch.randn(B, Cin, H, W, device=dev)
+        w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
+        b = torch.randn(Cout, device=dev)
+        res = torch.randn(B, Cout, H, W, device=dev)
+        wT = torch.empty(lib.ap_conv2d_packed_elems(Cout, Cin, k, k, 1), device=dev)
+        N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), Cout, Cin, k, k, 1, N.stream()))
+        plain = torch.empty(B, Cout, H, W, device=dev)
+        N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(res), N.ptr(plain), B, Cin, H, W, Cout, k, k, 1, k // 2, 1, 0, Cin, 0,
+                                  N.stream()))
+        wide = torch.full((B, Cout + extra, H, W), 7.0, device=dev)
+        N.check(lib.ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(res), N.ptr(wide), B, Cin, H, W, Cout, k, k, 1, k // 2, 1, 0, Cin, 0,
+                                        Cout + extra, coff, N.stream()))
+        assert torch.equal(wide[:, coff:coff + Cout], plain), (B, Cin, H, W, Cout, k)
+        rest = torch.cat([wide[:, :coff], wide[:, coff + Cout:]], 1)
+        assert bool((rest == 7.0).all())
+    # Cin % 16 != 0: not a layer of the streamed-weight kernel -> refused, nothing written
+    x = torch.randn(2, 24, 8, 8, device=dev)
+    w = torch.randn(64, 24, 3, 3, device=dev)
+    wT = torch.empty(lib.ap_conv2d_packed_elems(64, 24, 3, 3, 1), device=dev)
+    N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), 64, 24, 3, 3, 1, N.stream()))
+    wide = torch.zeros(2, 96, 8, 8, device=dev)
+    assert lib.ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), None, None, N.ptr(wide), 2, 24, 8, 8, 64, 3, 3, 1, 1, 1, 0, 24, 0, 96, 0, N.stream()) == -22
+    assert float(wide.abs().max()) == 0.0
