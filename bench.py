@@ -79,6 +79,60 @@ PMC_FILES = {"f32": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3
              "bf16": ["r3_bf16_pmc_traffic.json", "r2_bf16_pmc_traffic.json"]}
 
 
+class PowerSampler:
+    """Board power and shader clock of GPU 0 while a leg runs (`rocm-smi` polled from a side thread every 0.5 s: a host process,
+    nothing on the GPU's queues) -> the `power` object of that leg: the bf16 / f32s / f32h block kernels sit at the package's
+    power cap and the firmware lowers the clock under them, and the line should say so itself.  None when
+    rocm-smi is missing or prints nothing usable."""
+
+    def __init__(self, device_index=0):
+        import shutil
+        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self.dev = device_index
+        self.samples, self.stop, self.thread = [], False, None
+
+    def _read(self, extra=()):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run([self.exe, "-d", str(self.dev), "--showpower", "--showclocks", *extra], capture_output=True, text=True,
+                                 timeout=10).stdout
+        except Exception:
+            return None, None, None
+        p = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", out)
+        c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        m = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", out)
+        return (float(p.group(1)) if p else None, int(c.group(1)) if c else None, float(m.group(1)) if m else None)
+
+    def __enter__(self):
+        if self.exe:
+            import threading
+
+            def loop():
+                while not self.stop:
+                    w, c, _ = self._read()
+                    if w is not None and c is not None:
+                        self.samples.append((w, c))
+                    time.sleep(0.5)
+            self.thread = threading.Thread(target=loop, daemon=True)
+            self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        if self.thread:
+            self.thread.join(timeout=15)
+
+    def result(self):
+        if not self.samples:
+            return None
+        ws, cs = [w for w, _ in self.samples], [c for _, c in self.samples]
+        cap = self._read(("--showmaxpower",))[2]
+        return {"board_W_mean": round(sum(ws) / len(ws), 1), "board_W_max": round(max(ws), 1), "cap_W": cap,
+                "sclk_MHz_mean": round(sum(cs) / len(cs)), "sclk_MHz_min": min(cs), "samples": len(ws),
+                "source": "rocm-smi --showpower --showclocks polled every 0.5 s over the timed region"}
+
+
 def pmc_traffic(B, precision="f32"):
     """HBM-side bytes per residual-block launch from the newest committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 calibration, + WRITE_SIZE), scaled from the 512-clip launch it was measured on -> (bytes or None, source).
@@ -215,13 +269,14 @@ def bench_config4(dev, steps, B=256, n=5):
         y = system(x, True)                                             # warm-up: lowering, weight packing
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(steps):
-            y = system(x, True)
-        e1.record()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        with PowerSampler(dev.index or 0) as ps:
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                y = system(x, True)
+            e1.record()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
     assert y.shape == (B, 10) and torch.isfinite(y).all()
     ev_ms = e0.elapsed_time(e1) / steps
     gflop = n * UNET_GFLOP_PER_EVAL + RESNEXT29_GFLOP
@@ -251,7 +306,7 @@ def bench_config4(dev, steps, B=256, n=5):
     return {"workload": f"mel-dB front-end -> Improved-Diffusion UNet DDPM n={n} (ImprovedDiffusionDDPM) -> ResNeXt-29 8x64d, "
                         f"batch={B}, fp32 MFMA conv-as-GEMM, 1 s @ 16 kHz clips",
             "value": round(B * steps / el, 3), "unit": "utterances/s", "steps": steps, "warmup": 1,
-            "ms_per_step": round(el * 1e3 / steps, 3), "dtype": "f32",
+            "ms_per_step": round(el * 1e3 / steps, 3), "dtype": "f32", "power": ps.result(),
             "roofline": {"bound": "mfma", "kernel": f"conv-as-GEMM family (every conv / linear layer of the step); dominant: {names[dom]}",
                          "achieved": round(ktf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ktf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
@@ -364,11 +419,13 @@ def main():
                 step()
             N.check(eng.lib.ap_profile_enable(eng.ctx, 1))
             fence()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                lp = step()
-            fence()
-            elapsed = time.perf_counter() - t0
+            with PowerSampler(local) as ps:                       # (rank 0 reports; the sampler is a host-side poll)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    lp = step()
+                fence()
+                elapsed = time.perf_counter() - t0
+            run_mode.power = ps.result()
         tot_ms, launches = C.c_double(), C.c_int64()
         N.check(eng.lib.ap_profile_read(eng.ctx, C.byref(tot_ms), C.byref(launches)))
         N.check(eng.lib.ap_profile_enable(eng.ctx, 0))
@@ -421,6 +478,7 @@ def main():
         return roof
 
     elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
+    head_power = run_mode.power
     ranks = rank_evidence(use_dist, run_mode.local_elapsed, device_descriptor(torch, local), "nccl")
     # the other arithmetic modes of the same path, measured in the same run (N = 1 only: they are extra evidence,
     # not the headline): same inputs, same chain, same timing brackets
@@ -436,7 +494,8 @@ def main():
                 st = max(1, min(args.steps, 3))
                 e2, k2, l2 = run_mode(prec, st, min(args.warmup, 1))
             others[prec] = {"arithmetic": PREC_NAME[prec], "value": round(B * st / e2, 3), "unit": "utterances/s",
-                            "steps": st, "ms_per_step": round(e2 * 1e3 / st, 3), "roofline": roofline(prec, k2, l2)}
+                            "steps": st, "ms_per_step": round(e2 * 1e3 / st, 3), "roofline": roofline(prec, k2, l2),
+                            "power": run_mode.power}
 
     other_configs = {}
     if world == 1 and not args.no_other_configs:
@@ -447,7 +506,7 @@ def main():
             "workload": f"DiffWave VP-SDE (RevDiffWave Euler chain) n=10 + M5 classify, batch={B}, bf16 MFMA operands / fp32 "
                         "accumulate and storage, 1 s @ 16 kHz clips",
             "value": round(B * st / e3, 3), "unit": "utterances/s", "steps": st, "warmup": 1,
-            "ms_per_step": round(e3 * 1e3 / st, 3), "dtype": "bf16", "roofline": roofline("bf16", k3, l3)}
+            "ms_per_step": round(e3 * 1e3 / st, 3), "dtype": "bf16", "roofline": roofline("bf16", k3, l3), "power": run_mode.power}
         net.set_precision(args.precision)
         other_configs["configs[4]"] = bench_config4(dev, max(1, min(args.steps, 5)))
 
@@ -466,6 +525,7 @@ def main():
                        "global_batch": world * B, "clip_samples": L, "reverse_steps": n,
                        "parallelism": f"utterance-sharded x{world}, logits all_gather"},
             "roofline": roof,
+            "power": head_power,
             "ranks": ranks,
         }
         if others:
