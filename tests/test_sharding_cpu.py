@@ -79,3 +79,14 @@ def test_bench_self_launches_its_ranks_as_children_and_prints_one_line():
     assert len(rk["rank_elapsed_s"]) == 2 and rk["rank_elapsed_min_s"] <= rk["rank_elapsed_max_s"]
     assert [d["index"] for d in rk["devices"]] == [0, 1]
     assert out["ms_per_step"] * out["steps"] >= rk["rank_elapsed_min_s"] * 1e3 * 0.5
+
+
+def test_bench_power_sampler_is_optional_evidence():
+    """bench.py's per-leg `power` object (board power / cap / shader clock polled from rocm-smi) must never be a reason for a leg
+    to fail: without a GPU driver (this container) or without rocm-smi the sampler yields None."""
+    import time
+    import bench
+    with bench.PowerSampler(0) as ps:
+        time.sleep(0.1)
+    r = ps.result()
+    assert r is None or {"board_W_mean", "board_W_max", "cap_W", "sclk_MHz_mean", "samples"} <= set(r)
