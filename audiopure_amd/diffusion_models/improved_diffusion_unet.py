@@ -304,7 +304,7 @@ class UNetModel(nn.Module):
             skip = hs.pop()
             Bc, C1, H, W = h.shape
             C2 = skip.shape[1]
-            if cat is not None and h.data_ptr() == cat.data_ptr() and not h.is_contiguous():     # h already sits in cat[:, :C1]
+            if cat is not None and h.data_ptr() == cat.data_ptr():      # h is the view cat[:, :C1] its producer wrote in place
                 assert cat.shape[1] == C1 + C2
             else:
                 cat = torch.empty((Bc, C1 + C2, H, W), device=dev, dtype=torch.float32)
