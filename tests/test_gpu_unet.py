@@ -94,6 +94,21 @@ def test_full_unet_matches_reference_golden(dev, gold):
     assert rel_err(eps.cpu().numpy(), gold["full/eps_t37"]) < TOL
 
 
+def test_full_unet_with_in_place_concatenation_is_bit_identical_to_the_copying_form(dev):
+    """At inference the block that produces h writes it straight into the buffer of `th.cat([h, hs.pop()], dim=1)`
+    (improved_diffusion/unet.py:490-491; ap_conv2d_fwd_slice); with a tape (forward_save, the gradient's forward pass) both halves
+    are copied.  Same kernels, same arithmetic: the two evaluations must agree bit for bit (batch 1: the slice view is
+    "contiguous" there; batch 3: it is not)."""
+    full = synth_init(create_model(**model_and_diffusion_defaults()), 0).to(dev)
+    for B in (1, 3):
+        x = torch.from_numpy(synth.uniform(f"ipc{B}", (B, 1, 32, 32), 1, -1, 1)).to(dev)
+        t = torch.tensor([37.0] * B)
+        with torch.no_grad():
+            direct = full(x, t)
+            taped, _ = full.forward_save(x, t)
+        assert torch.equal(direct, taped), B
+
+
 def test_spec_purifier_matches_oracle(dev):
     from oracle import unet_oracle as U
     m = mini_unet()
