@@ -85,9 +85,9 @@ class PowerSampler:
     power cap and the firmware lowers the clock under them, and the line should say so itself.  None when
     rocm-smi is missing or prints nothing usable."""
 
-    def __init__(self, device_index=0):
+    def __init__(self, device_index=0, enabled=True):
         import shutil
-        self.exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+        self.exe = (shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)) if enabled else None
         self.dev = device_index
         self.samples, self.stop, self.thread = [], False, None
 
@@ -419,7 +419,7 @@ def main():
                 step()
             N.check(eng.lib.ap_profile_enable(eng.ctx, 1))
             fence()
-            with PowerSampler(local) as ps:                       # (rank 0 reports; the sampler is a host-side poll)
+            with PowerSampler(local, enabled=rank == 0) as ps:    # (rank 0's GPU only: one host-side poll per job)
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     lp = step()
