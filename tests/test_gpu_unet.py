@@ -59,6 +59,15 @@ def test_primitives_match_torch(dev):
         N.check(lib.ap_groupnorm_nchw(N.ptr(xd), N.ptr(gd), N.ptr(bd), N.ptr(sd_) if use_ss else None, N.ptr(y), B, C_, H * W, G, 1e-5,
                                       act, N.stream()))
         assert rel_err(y.cpu().numpy(), ref.numpy()) < 3e-6, (B, C_, H, W, G, act, use_ss)
+    # a 4-byte-aligned (not 16-byte-aligned) input takes the three-pass kernel: same result
+    flat = torch.zeros(2 * 64 * 8 * 8 + 1, device=dev)
+    xm = flat[1:].view(2, 64, 8, 8)
+    xm.copy_(torch.from_numpy(synth.uniform("gnmis", (2, 64, 8, 8), 1, -2, 2)))
+    g64, b64 = torch.from_numpy(synth.uniform("gng", (64,), 1, 0.5, 1.5)).to(dev), torch.from_numpy(synth.uniform("gnb", (64,), 1)).to(dev)
+    ym = torch.empty(2, 64, 8, 8, device=dev)
+    N.check(lib.ap_groupnorm_nchw(N.ptr(xm), N.ptr(g64), N.ptr(b64), None, N.ptr(ym), 2, 64, 64, 32, 1e-5, 2, N.stream()))
+    refm = F.group_norm(xm.cpu(), 32, g64.cpu(), b64.cpu(), 1e-5)
+    assert rel_err(ym.cpu().numpy(), (refm * torch.sigmoid(refm)).numpy()) < 3e-6
     # channel-slice copy (torch.cat / slices): the 16-byte 2-D form and the element form (H W = 25, an unaligned offset)
     for (B, C_, HW, scs, sco, dcs, dco) in ((3, 8, 64, 8, 0, 20, 12), (2, 5, 1024, 9, 3, 5, 0), (2, 6, 25, 7, 1, 9, 2), (2, 3, 6, 4, 1, 7, 3),
                                             (4, 10, 1, 16, 4, 12, 1), (2, 8, 1, 16, 4, 12, 4)):
