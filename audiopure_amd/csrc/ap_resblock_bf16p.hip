@@ -710,6 +710,9 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
           if constexpr (!(DBG & 0x2000)) __builtin_amdgcn_s_setprio(0);
           mark_half(ch);
         }
+        if constexpr ((DBG & 2048) != 0 && (DBG & 0x8000000) != 0) {   // tools: stamps 42..47 = start of chunk 3's k-steps (DBG 2048 + 0x8000000)
+          if (ch == 3) mark(42 + ks);
+        }
         if (ks == PK) {
           if constexpr (!LAST) pack_ptv(ch + 1);
           __builtin_amdgcn_sched_barrier(0);
@@ -1177,7 +1180,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   else if ((g_dbg_bf16 & 0x7000000) == 0x3000000) AP_P_LAUNCH(0x3000000);
   else if ((g_dbg_bf16 & 0x7000000) == 0x5000000) AP_P_LAUNCH(0x5000000);
   else
-  switch (g_dbg_bf16 & 0xefff) {
+  switch (g_dbg_bf16 & 0x800efff) {
     case 0: AP_P_LAUNCH(0); break;
     case 1: AP_P_LAUNCH(1); break;
     case 2: AP_P_LAUNCH(2); break;
@@ -1208,6 +1211,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
     case 1024: AP_P_LAUNCH(1024); break;
     case 2048: AP_P_LAUNCH(2048); break;
     case 2048 + 384: AP_P_LAUNCH(2048 + 384); break;
+    case 2048 + 0x8000000: AP_P_LAUNCH(2048 + 0x8000000); break;
     case 1024 + 384: AP_P_LAUNCH(1024 + 384); break;
     case 0x2000: AP_P_LAUNCH(0x2000); break;
     case 0x4000: AP_P_LAUNCH(0x4000); break;

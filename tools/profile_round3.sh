@@ -24,6 +24,7 @@ for prec in f32 f32s f32h bf16; do
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d "$repo/$out/sq_$prec" -o r -- python3 "$repo/tools/run_resblock_layers.py" $B $prec $REPS $LAYERS > "$repo/$out/sq_$prec.log" 2>&1
 done
 timeout 300 python3 "$repo/tools/trace_resblock_bf16p.py" 256 9 > "$repo/$out/phase_trace.txt" 2>&1
+timeout 300 python3 "$repo/tools/trace_resblock_bf16p.py" 256 9 0x8000000 > "$repo/$out/kstep_trace.txt" 2>&1
 timeout 600 python3 "$repo/tools/dbg_resblock_bf16.py" 256 0 4096 1 2 3 4 8 128 256 384 512 1024 8192 > "$repo/$out/ablation.txt" 2>&1
 { timeout 300 python3 "$repo/tools/cmp_bf16_kernels.py" 4; for L in 130 1001 1002 1003 23457; do echo "L = $L"; AP_CMP_L=$L timeout 300 python3 "$repo/tools/cmp_bf16_kernels.py" 2 0 1 3 5 9 11; done; } > "$repo/$out/cmp_kernels.txt" 2>&1
 { timeout 300 python3 "$repo/tools/ab_bf16w.py" 256 3 2 5 9 11; timeout 300 python3 "$repo/tools/trace_resblock_bf16w.py" 256 9; timeout 300 python3 "$repo/tools/ablate_bf16w.py" 256 9 2; } > "$repo/$out/bf16w_experiment.txt" 2>&1

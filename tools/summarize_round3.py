@@ -121,3 +121,4 @@ text("bf16_energy_ablation.txt", "r3_bf16_energy_ablation.txt")
 text("bf16_operand_images_experiment.txt", "r3_bf16_operand_images_experiment.txt")
 if os.path.exists(os.path.join(src, "cfg4_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "cfg4_kernel_stats.csv"), os.path.join(P, "r3_cfg4_kernel_stats.csv"))
+text("kstep_trace.txt", "r3_bf16_kstep_trace.txt")

@@ -7,7 +7,7 @@ from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNe
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 layer = int(sys.argv[2]) if len(sys.argv) > 2 else 9
-extra = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+extra = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
 L = 16000
 h = torch.randn(B, 256, L, device=dev); ho = torch.empty_like(h); sk = torch.zeros_like(h)
 pt = torch.randn(256, device=dev)
@@ -48,3 +48,9 @@ print("median heavy+light per wave:", np.median(arr, (0, 1)).astype(int))
 print("median barrier wait per wave:", np.median(bar, (0, 1)).astype(int))
 rel = t[:, :, 4:25:3] - t[:, :1, 4:25:3]
 print("arrival at the chunk barrier relative to wave 0 (median per wave):", np.median(rel, (0, 2)).astype(int))
+
+if extra & 0x8000000:                                     # per-k-step stamps of chunk 3 (slots 42..47; the chunk's end is stamp 13)
+    ks = np.stack([t[:, :, 43 + i] - t[:, :, 42 + i] for i in range(5)] + [t[:, :, 13] - t[:, :, 47]], 0)      # [k-step][wg][wave]
+    print("chunk 3, cycles per k-step (8 MFMAs = 256 cycles of matrix pipe per wave; median over workgroups), per wave:")
+    for i in range(6):
+        print(f"  k-step {i}:", np.median(ks[i], 0).astype(int), " all waves:", int(np.median(ks[i])))
