@@ -284,12 +284,16 @@ __global__ __launch_bounds__(256) void conv2d_f32_big_kernel(ConvArgs a) {
 // layers): the "gather" is a plain row of pixels, so a thread stages four consecutive pixels of a channel with ONE 16-byte
 // load and one ds_write_b128 -- two loads per thread and chunk instead of eight.
 template <int BM, int BN, bool BUF = true, bool P1 = false>
-__global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag, unsigned x_bytes,
+__global__ __launch_bounds__(256, 5) void conv2d_f32_big2_kernel(ConvArgs a, const float *__restrict__ afrag, unsigned x_bytes,
                                                                  unsigned a_bytes) {
   // 2 x 2 waves, each (BM/2 rows x BN/2 columns): BM x BN = 128 x 128, 128 x 64 (layers with few tiles), 64 x 128
   // (64 <= Cout/g < 128: ResNeXt's grouped 3x3)
   constexpr int BK = 16, NX = BM / 64, NY = BN / 64, EPT = BK * BN / 256, KSTEP = 256 / BN;
-  __shared__ float Bs[2][BK][BN];
+  // im2col tile: P1 keeps [k'][column] (its staging writes four pixels of one k' at once, 4-byte fragment reads); the gather form
+  // keeps [column][k'] with 80-byte rows (conflict-free 16-byte writes of a thread's EPT consecutive k' and 16-byte fragment reads)
+  constexpr int RS = BK + 4;
+  __shared__ __attribute__((aligned(16))) float Bs_[P1 ? 2 * BK * BN : 2 * BN * RS];
+  auto Bs = [&](int buf, int k, int col) -> float & { return Bs_[P1 ? (buf * BK + k) * BN + col : (buf * BN + col) * RS + k]; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int j = lane & 31, hh = lane >> 5;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   const int HoWo = a.Ho * a.Wo, N = a.B * HoWo;
   const int g = a.splits > 1 ? 0 : blockIdx.z, zs = a.splits > 1 ? blockIdx.z : 0;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int nl = tid & (BN - 1), kq = tid / BN;        // element i of a thread: chunk row kq + KSTEP i, column nl
+  const int nl = tid & (BN - 1), kq = (tid / BN) * (P1 ? 1 : EPT);   // gather form: a thread stages k' = kq .. kq + EPT - 1 of column nl
   const int n = n0 + nl;
   const bool nvalid = n < N;
   const int bb = nvalid ? n / HoWo : 0, pp = nvalid ? n % HoWo : 0;
@@ -355,12 +359,12 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
       const unsigned voff = ok ? (xb_off + (unsigned)(c0 * HW + iy * a.W + ix)) * 4u : 0x80000000u;   // out of range -> 0
 #pragma unroll
       for (int i = 0; i < EPT; i++)
-        br[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, KSTEP * i * HW * 4, 0));
+        br[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff, i * HW * 4, 0));
     } else {
       const float *p = xb + (size_t)c0 * HW + (ok ? iy * a.W + ix : 0);
 #pragma unroll
       for (int i = 0; i < EPT; i++) {
-        const float v = p[(size_t)(KSTEP * i) * HW];
+        const float v = p[(size_t)i * HW];
         br[i] = ok ? v : 0.f;
       }
     }
@@ -379,11 +383,12 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
   auto store_b = [&](int buf) {
     if constexpr (P1) {
 #pragma unroll
-      for (int i = 0; i < NP1; i++) *reinterpret_cast<f32x4 *>(&Bs[buf][kq1 + R1 * i][4 * nq1]) = br4[i];
+      for (int i = 0; i < NP1; i++) *reinterpret_cast<f32x4 *>(&Bs(buf, kq1 + R1 * i, 4 * nq1)) = br4[i];
       return;
     }
 #pragma unroll
-    for (int i = 0; i < EPT; i++) Bs[buf][kq + KSTEP * i][nl] = br[i];
+    for (int v = 0; v < EPT / 4; v++)
+      *reinterpret_cast<f32x4 *>(&Bs(buf, kq + 4 * v, nl)) = f32x4{br[4 * v], br[4 * v + 1], br[4 * v + 2], br[4 * v + 3]};
   };
   f32x16 acc[NX][NY];
 #pragma unroll
@@ -392,17 +397,33 @@ __global__ __launch_bounds__(256, 3) void conv2d_f32_big2_kernel(ConvArgs a, con
     for (int y_ = 0; y_ < NY; y_++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[x_][y_][r] = 0.f;
+  // step (q, e) of a chunk: k' = 8 q + 4 hh + e (the order of the fragment image)
   auto compute = [&](const f32x4(&aa)[NX][2], int buf) {
 #pragma unroll
-    for (int s = 0; s < BK / 2; s++) {
-      float bf[NY];
+    for (int q = 0; q < BK / 8; q++) {
+      if constexpr (!P1) {                                      // one column tile at a time: four operand registers live, eight MFMAs per read
 #pragma unroll
-      for (int t = 0; t < NY; t++) bf[t] = Bs[buf][2 * s + hh][32 * NY * wn + 32 * t + j];
+        for (int y_ = 0; y_ < NY; y_++) {
+          const f32x4 bq = *reinterpret_cast<const f32x4 *>(&Bs(buf, 8 * q + 4 * hh, 32 * NY * wn + 32 * y_ + j));
 #pragma unroll
-      for (int x_ = 0; x_ < NX; x_++)
+          for (int e = 0; e < 4; e++)
 #pragma unroll
-        for (int y_ = 0; y_ < NY; y_++)
-          acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x_][s >> 2][s & 3], bf[y_], acc[x_][y_], 0, 0, 0);
+            for (int x_ = 0; x_ < NX; x_++)
+              acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x_][q][e], bq[e], acc[x_][y_], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float bf[NY];
+#pragma unroll
+          for (int t = 0; t < NY; t++) bf[t] = Bs(buf, 8 * q + 4 * hh + e, 32 * NY * wn + 32 * t + j);
+#pragma unroll
+          for (int x_ = 0; x_ < NX; x_++)
+#pragma unroll
+            for (int y_ = 0; y_ < NY; y_++)
+              acc[x_][y_] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[x_][q][e], bf[y_], acc[x_][y_], 0, 0, 0);
+        }
+      }
     }
   };
 
@@ -706,7 +727,10 @@ __global__ void conv_pack_splith_kernel(const float *__restrict__ w, const float
 }
 
 // w [Cout][Cin/g][kh][kw] (* scale) -> A-operand fragments of v_mfma_f32_32x32x2_f32 in tap-major K order:
-// [group][row tile MT][k'/8][lane 64][4], element e of quad q = k' pair 4q + e, lane = (row i, half h): k' = 2 pair + h
+// [group][row tile MT][k'/8][lane 64][4], lane = (row i, half h), element e of octet q: k' = 8 q + 4 h + e -- MFMA step (q, e) takes
+// k' = 8q + e from lane half 0 and 8q + 4 + e from half 1, so that a lane's B operands of four consecutive steps are four
+// CONSECUTIVE k' of its column: one ds_read_b128 from a [column][k'] image (every LDS read that lands in VGPRs costs the matrix
+// pipe 10-19 cycles on its SIMD; four steps per read instead of one: tools/micro/mfma_f32_lds.hip, 0.85 -> 0.95 of peak)
 __global__ void conv_pack_frag_kernel(const float *__restrict__ w, const float *__restrict__ scale,
                                       float *__restrict__ out, int Cout, int Cg, int KK, int groups) {
   const int Mg = Cout / groups, MT = (Mg + 31) / 32, Kg = Cg * KK, KQ = Kg / 8;
@@ -718,7 +742,7 @@ __global__ void conv_pack_frag_kernel(const float *__restrict__ w, const float *
   const int q = rest % KQ; rest /= KQ;
   const int mt = rest % MT, g = rest / MT;
   const int i = lane & 31, h = lane >> 5;
-  const int kp = 2 * (4 * q + e) + h;                           // k' = r Cg + ci
+  const int kp = 8 * q + 4 * h + e;                             // k' = r Cg + ci
   const int r = kp / Cg, ci = kp - r * Cg;
   const int m = 32 * mt + i;
   float v = 0.f;
