@@ -310,6 +310,8 @@ def bench_config4(dev, steps, B=256, n=5):
             "roofline": {"bound": "mfma", "kernel": f"conv-as-GEMM family (every conv / linear layer of the step); dominant: {names[dom]}",
                          "achieved": round(ktf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ktf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "attainable": "the same matrix instruction fed from LDS reaches 0.84-0.94 of this peak in a bare loop "
+                                       "(profiles/r3_mfma_f32_operand_delivery.txt)",
                          "note": "per-kernel: algorithmic flops (2 N M K) of every ap_conv2d_fwd launch of one step / the HIP-event "
                                  "time of those launches on their launch stream (a separate pass of the same step, outside the "
                                  "timed region); by_kernel gives each kernel class its own rate",
@@ -447,7 +449,9 @@ def main():
         if precision == "f32":
             roof = {"bound": "mfma", "kernel": "resblock_f32_kernel<256,64>", "achieved": round(achieved, 2),
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": traffic}
+                    "traffic": traffic,
+                    "note": "v_mfma_f32_32x32x2_f32 issues at 0.98 of this peak from registers and at 0.84-0.94 when its operands "
+                            "arrive from LDS (4-byte / 16-byte reads): profiles/r3_mfma_f32_operand_delivery.txt, DESIGN.md 3.5"}
         elif precision == "f32s":
             # fp32 operands as three bf16 parts, 6 bf16 MFMAs per fp32 MFMA-equivalent: the ceiling for ALGORITHMIC
             # flops is the dense bf16 MFMA peak / 6
