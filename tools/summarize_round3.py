@@ -123,3 +123,4 @@ if os.path.exists(os.path.join(src, "cfg4_kernel_stats.csv")):
     shutil.copy(os.path.join(src, "cfg4_kernel_stats.csv"), os.path.join(P, "r3_cfg4_kernel_stats.csv"))
 text("kstep_trace.txt", "r3_bf16_kstep_trace.txt")
 text("mfma_power_calibration.txt", "r3_mfma_power_calibration.txt")
+text("mfma_hbm_mix.txt", "r3_mfma_hbm_mix.txt")
