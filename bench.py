@@ -478,7 +478,7 @@ def main():
                     "note": "the kernel runs at the board's 1400 W power cap (see this leg's `power`); calibrated with bare MFMA and "
                             "HBM-copy kernels (profiles/r3_mfma_power_calibration.txt: ~0.63 pJ per bf16 flop on random operands, ~120 pJ "
                             "per HBM byte) the ceiling of this algorithm under the cap is 0.48-0.54 of the 8 TB/s roofline; a synthetic kernel with the same "
-                            "MFMA : HBM mix and nothing else measures 0.46-0.47 (profiles/r3_mfma_hbm_mix.txt, DESIGN.md 3.4)"}
+                            "MFMA : HBM mix and nothing else measures 0.46-0.48 (profiles/r3_mfma_hbm_mix.txt, DESIGN.md 3.4)"}
         roof.update({"traffic_source": traffic_source, "launches": launches, "clips_per_launch": B, "avg_launch_ms": round(k_ms, 4),
                      "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,
                      "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),

@@ -1,7 +1,7 @@
 // The bf16 block's mix without the block: per "tile" and CU 4096 v_mfma_f32_32x32x16_bf16 on random operands (134 MFLOP) beside
 // 262 KB of fp32 read from HBM and 262 KB written back (streams touched once, like h / skip in and h' / skip out), nothing else --
 // no weight stream, no staging, no gate, no transposes.  What tile rate does the 1400 W cap allow THAT?  (rocm-smi polled meanwhile.)
-//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_hbm_mix.hip -o /tmp/mfma_hbm_mix -lpthread && /tmp/mfma_hbm_mix [seconds]
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_hbm_mix.hip -o /tmp/mfma_hbm_mix -lpthread && /tmp/mfma_hbm_mix [seconds] [workgroups per CU]
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <chrono>
@@ -69,7 +69,8 @@ static bool smi(double &w, double &mhz) {
 
 int main(int argc, char **argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 4.0;
-  const int nblk = 256, tiles = 125;                              // 125 tiles per CU and launch = the block kernel's 256-clip launch
+  const int bpc = argc > 2 ? atoi(argv[2]) : 1;                   // workgroups per CU (1 or 2)
+  const int nblk = 256 * bpc, tiles = 125 / bpc;                  // ~125 tiles per CU and launch = the block kernel's 256-clip launch
   std::vector<unsigned short> h(8 * 4096 * 8);
   srand(1);
   for (auto &v : h) { float f = (rand() / (float)RAND_MAX) * 2.f - 1.f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }

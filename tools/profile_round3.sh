@@ -36,6 +36,6 @@ cp "$repo/$out"/cfg4_stats/*kernel_stats.csv "$repo/$out/cfg4_kernel_stats.csv" 
 { timeout 300 python3 "$repo/tools/power_check.py" 5 256; AP_ZERO=1 timeout 300 python3 "$repo/tools/power_check.py" 4 256; timeout 200 python3 "$repo/tools/power_check_conv.py" 4; } 2>&1 | grep -v amdgpu.ids > "$repo/$out/power_by_mode.txt"
 timeout 400 python3 "$repo/tools/power_ablate_bf16.py" 256 3 2>&1 | grep -v amdgpu.ids > "$repo/$out/bf16_energy_ablation.txt"
 { hipcc --offload-arch=gfx950 -O3 "$repo/tools/micro/mfma_power.hip" -o /tmp/mfma_power -lpthread 2>/dev/null && timeout 200 /tmp/mfma_power 5; } > "$repo/$out/mfma_power_calibration.txt" 2>&1
-{ hipcc --offload-arch=gfx950 -O3 "$repo/tools/micro/mfma_hbm_mix.hip" -o /tmp/mfma_hbm_mix -lpthread 2>/dev/null && timeout 200 /tmp/mfma_hbm_mix 5; } > "$repo/$out/mfma_hbm_mix.txt" 2>&1
+{ hipcc --offload-arch=gfx950 -O3 "$repo/tools/micro/mfma_hbm_mix.hip" -o /tmp/mfma_hbm_mix -lpthread 2>/dev/null && { echo "== one workgroup per CU"; timeout 200 /tmp/mfma_hbm_mix 5 1; echo "== two workgroups per CU"; timeout 200 /tmp/mfma_hbm_mix 5 2; }; } > "$repo/$out/mfma_hbm_mix.txt" 2>&1
 timeout 400 python3 "$repo/tools/ab_bf16_ub.py" 256 2 2>&1 | grep -v amdgpu.ids > "$repo/$out/bf16_operand_images_experiment.txt"
 ls "$repo/$out"
