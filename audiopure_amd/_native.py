@@ -59,6 +59,10 @@ SIGNATURES = {
     "ap_init_conv": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_resblock_fwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_resblock_fwd_save": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "ap_resblock_fwd_gate": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _i, _i, _vp]),
+    "ap_skip_gemm": (_i, [_vp, _i, _i, _vp, _fp, _i, _i, _i, _vp]),
+    "ap_ctx_set_skip_group": (_i, [_vp, _i]),
+    "ap_profile_read_split": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ap_final_affine": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),
     "ap_affine_noise": (_i, [_fp, _fp, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),
     "ap_eps_fwd": (_i, [_vp, _fp, _f, _fp, _i, _i, _vp, _sz, _vp]),
@@ -193,15 +197,18 @@ CONV_WS_BYTES = 64 << 20
 
 
 def use_conv_workspace(device) -> None:
-    """Hand the library this device's split-K workspace (``ap_conv2d_set_workspace``; allocated once per device by torch's
-    caching allocator and kept alive here -- the library itself allocates nothing).  Called at the entry of every native
-    conv-net forward, so the pointer the library holds always belongs to the device the launches go to."""
+    """Register this device's split-K workspace with the library (``ap_conv2d_set_workspace``: one slot per HIP device, keyed by
+    the device current at the call and at each launch; allocated once per device by torch's caching allocator and kept alive
+    here -- the library itself allocates nothing).  Called at the entry of every native conv-net forward and of the 1-D
+    backward GEMMs; a no-op once the device has its buffer."""
     import torch
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _CONV_WS.get(idx)
-    if ws is None:
-        ws = _CONV_WS[idx] = torch.empty(CONV_WS_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
-    check(lib().ap_conv2d_set_workspace(ws.data_ptr(), CONV_WS_BYTES), "ap_conv2d_set_workspace")
+    if idx in _CONV_WS:
+        return
+    with torch.cuda.device(idx):
+        ws = torch.empty(CONV_WS_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+        check(lib().ap_conv2d_set_workspace(ws.data_ptr(), CONV_WS_BYTES), "ap_conv2d_set_workspace")
+    _CONV_WS[idx] = ws
 
 
 def stream() -> int:

@@ -404,7 +404,15 @@ class NativeConvNet(nn.Module):
         live: nothing to fold), on CPU with CPU parameters, or once its trace meets an operator the library has no
         kernel for, the caller's own module runs as it is -- said once, never silently mixed with the native path.
         An explicitly constructed ``NativeConvNet(module, chw)`` lowers in ``__init__`` and raises there instead."""
-        if self._foreign or self.training:
+        if self.training and not self._foreign:
+            if not getattr(self, "_warned_train", False):
+                import warnings
+                warnings.warn(f"{type(self.module).__name__}: train() mode -- the caller's module runs on PyTorch operators; the "
+                              "native plan is re-lowered from the parameters at the next eval() forward", RuntimeWarning, stacklevel=2)
+                self._warned_train = True
+            self.plan, self._dev_weights = None, None            # the plan holds weights folded at lowering: stale after a training step
+            return self.module(x)
+        if self._foreign:
             return self.module(x)
         if not x.is_cuda and self.plan is None and all(not p.is_cuda for p in self.module.parameters()):
             return self.module(x)
@@ -417,8 +425,8 @@ class NativeConvNet(nn.Module):
                 self.input_chw = tuple(x.shape[1:])
                 self.plan = lower(self.module, self.input_chw)
                 self._dev_weights = None
-            except NotImplementedError as e:
-                import warnings
+            except (NotImplementedError, RuntimeError, TypeError, ValueError, KeyError, IndexError, AttributeError) as e:
+                import warnings                                  # (a trace can fail in other ways than "no kernel for this operator")
                 warnings.warn(f"{type(self.module).__name__}: not lowered onto the HIP library ({e}); the module runs as "
                               "the caller built it (PyTorch operators)", RuntimeWarning, stacklevel=3)
                 self._foreign, self.plan, self.input_chw = True, None, None

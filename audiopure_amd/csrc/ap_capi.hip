@@ -107,6 +107,7 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->w1p_s = c->w2p_s = nullptr;
   c->profile = false;
   c->ev_used = 0;
+  c->skip_group = 0;
   const int T = cfg->T;
   // calc_diffusion_hyperparams (util.py:96-123), closed form in double rounded to fp32
   c->Beta.resize(T); c->Alpha.resize(T); c->Alpha_bar.resize(T); c->Sigma.resize(T);
@@ -149,18 +150,46 @@ extern "C" int ap_profile_enable(ap_ctx *ctx, int enable) {
   return 0;
 }
 
-extern "C" int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches) {
-  if (!ctx || !total_ms || !launches) { set_error("ap_profile_read: null argument"); return -22; }
-  double tot = 0.0;
+// per kind: [0] residual-block launches, [1] skip-GEMM launches of the deferred-skip form
+static int profile_sum(ap_ctx *ctx, double ms_by_kind[2], int64_t n_by_kind[2]) {
+  ms_by_kind[0] = ms_by_kind[1] = 0.0;
+  n_by_kind[0] = n_by_kind[1] = 0;
   for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
     AP_HIP(hipEventSynchronize(ctx->ev[i + 1]));
     float ms = 0.f;
     AP_HIP(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
-    tot += ms;
+    const int k = (i / 2 < ctx->ev_kind.size() && ctx->ev_kind[i / 2]) ? 1 : 0;
+    ms_by_kind[k] += ms;
+    n_by_kind[k] += 1;
   }
-  *total_ms = tot;
-  *launches = (int64_t)(ctx->ev_used / 2);
   ctx->ev_used = 0;
+  return 0;
+}
+
+extern "C" int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches) {
+  if (!ctx || !total_ms || !launches) { set_error("ap_profile_read: null argument"); return -22; }
+  double ms[2];
+  int64_t n[2];
+  int rc = profile_sum(ctx, ms, n);
+  if (rc) return rc;
+  *total_ms = ms[0] + ms[1];                                      // the skip GEMMs are part of the layers' work: their time is folded in,
+  *launches = n[0];                                               // the count stays "one per residual layer"
+  return 0;
+}
+
+extern "C" int ap_profile_read_split(ap_ctx *ctx, double *ms_by_kind, int64_t *launches_by_kind) {
+  if (!ctx || !ms_by_kind || !launches_by_kind) { set_error("ap_profile_read_split: null argument"); return -22; }
+  return profile_sum(ctx, ms_by_kind, launches_by_kind);
+}
+
+extern "C" int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group) {
+  if (!ctx) { set_error("ap_ctx_set_skip_group: null ctx"); return -22; }
+  if (layers_per_group < 0 || layers_per_group > ctx->NL) { set_error("ap_ctx_set_skip_group: %d outside [0, %d]", layers_per_group, ctx->NL); return -22; }
+  if (layers_per_group > 0 && (ctx->cfg.precision != AP_PREC_BF16 || ctx->C != 256 || ctx->S != 256)) {
+    set_error("ap_ctx_set_skip_group: the deferred-skip form is built for AP_PREC_BF16 with res = skip = 256 channels");
+    return -22;
+  }
+  ctx->skip_group = layers_per_group;
   return 0;
 }
 
@@ -296,6 +325,7 @@ extern "C" int ap_ctx_get_folded(ap_ctx *ctx, int which, int layer, float *out_d
 }
 
 // workspace: h_a [B C L] | h_b [B C L] | skip [B S L] | x_a [B L] | x_b [B L] | part_t [NL C + Eout]
+//            | AP_PREC_BF16 with a skip group G > 0: g images [G][B][L][C] bf16 (the deferred-skip form: ap_skipgemm_bf16.hip)
 //            | tools builds, AP_PREC_BF16: ub_a, ub_b [B][C/32][L][32] bf16 (the operand-image experiment: ap_resblock_bf16p.hip, UB)
 #ifdef AP_TOOLS
 namespace ap { extern int g_dbg_bf16; }
@@ -304,6 +334,8 @@ namespace {
 struct Ws {
   float *ha, *hb, *skip, *xa, *xb, *pt;
   void *uba, *ubb;
+  char *gimg;          // [G][B][L][C] bf16, or null
+  size_t gslot;        // bytes per slot
   size_t bytes;
 };
 inline size_t al(size_t n) { return (n + 63) & ~(size_t)63; }
@@ -319,6 +351,13 @@ Ws carve(const ap_ctx *ctx, void *base, int B, int L) {
   w.xb = p; p += xl;
   w.pt = p; p += pt;
   w.uba = w.ubb = nullptr;
+  w.gimg = nullptr;
+  w.gslot = 0;
+  if (ctx->cfg.precision == AP_PREC_BF16 && ctx->skip_group > 0) {
+    w.gslot = (size_t)B * L * ctx->C * 2;                       // (a multiple of 512 bytes)
+    w.gimg = (char *)p;
+    p += al(((size_t)ctx->skip_group * w.gslot + 3) / 4);
+  }
 #ifdef AP_TOOLS
   if (ctx->cfg.precision == AP_PREC_BF16) {
     const size_t ub = al(((size_t)B * ctx->C * L + 1) / 2);
@@ -364,6 +403,39 @@ int run_net(ap_ctx *ctx, const float *x, float step, const Ws &w, int B, int L, 
     return 0;
   }
 #endif
+  if (w.gimg) {
+    // deferred-skip form (AP_PREC_BF16): every block writes h' and its bf16 g image; after each group of G layers one GEMM adds
+    // the group's skip_conv outputs into skip (a plain store for the first group)
+    const int G = ctx->skip_group;
+    for (int n0 = 0; n0 < ctx->NL; n0 += G) {
+      const int nl = ctx->NL - n0 < G ? ctx->NL - n0 : G;
+      for (int n = n0; n < n0 + nl; n++) {
+        rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, hout, nullptr, 0, B, L, st, nullptr, nullptr,
+                             w.gimg + (size_t)(n - n0) * w.gslot);
+        if (rc) return rc;
+        float *t = hin; hin = hout; hout = t;
+      }
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (ctx->profile) {
+        if (ctx->ev_used + 2 > ctx->ev.size())
+          for (int i = 0; i < 2; i++) {
+            hipEvent_t e;
+            AP_HIP(hipEventCreate(&e));
+            ctx->ev.push_back(e);
+          }
+        e0 = ctx->ev[ctx->ev_used];
+        e1 = ctx->ev[ctx->ev_used + 1];
+        if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
+        ctx->ev_kind[ctx->ev_used / 2] = 1;
+        ctx->ev_used += 2;
+        AP_HIP(hipEventRecord(e0, st));
+      }
+      rc = launch_skipgemm_bf16(ctx, n0, nl, w.gimg, w.skip, n0 > 0, B, L, st);
+      if (e1) AP_HIP(hipEventRecord(e1, st));
+      if (rc) return rc;
+    }
+    return 0;
+  }
   for (int n = 0; n < ctx->NL; n++) {
     rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, hout, w.skip, n > 0, B, L, st);
     if (rc) return rc;
@@ -394,6 +466,22 @@ extern "C" int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const 
   if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd: layer=%d B=%d L=%d", layer, B, L); return -22; }
   if (h_in == h_out) { set_error("ap_resblock_fwd: h_out must not alias h_in"); return -22; }
   return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, skip, accumulate_skip, B, L, (hipStream_t)stream);
+}
+
+extern "C" int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
+                                    void *g_image, int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !h_in || !part_t_layer || !h_out || !g_image) { set_error("ap_resblock_fwd_gate: not loaded / null"); return -22; }
+  if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd_gate: layer=%d B=%d L=%d", layer, B, L); return -22; }
+  if (h_in == h_out) { set_error("ap_resblock_fwd_gate: h_out must not alias h_in"); return -22; }
+  if (ctx->cfg.precision != AP_PREC_BF16) { set_error("ap_resblock_fwd_gate: AP_PREC_BF16 only"); return -22; }
+  return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, nullptr, 0, B, L, (hipStream_t)stream, nullptr, nullptr, g_image);
+}
+
+extern "C" int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, float *skip, int accumulate_skip,
+                            int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !g_images || !skip) { set_error("ap_skip_gemm: not loaded / null"); return -22; }
+  if (ctx->cfg.precision != AP_PREC_BF16) { set_error("ap_skip_gemm: AP_PREC_BF16 only"); return -22; }
+  return launch_skipgemm_bf16(ctx, layer0, n_layers, g_images, skip, accumulate_skip, B, L, (hipStream_t)stream);
 }
 
 extern "C" int ap_resblock_fwd_save(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,

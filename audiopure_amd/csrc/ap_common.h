@@ -87,7 +87,9 @@ struct ap_ctx {
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
   bool profile;
   std::vector<hipEvent_t> ev;   // pairs (start, stop), one pair per launch since the last reset
+  std::vector<char> ev_kind;    // per pair: 0 residual-block launch, 1 skip-GEMM launch of the deferred-skip form
   size_t ev_used;
+  int skip_group;               // AP_PREC_BF16: layers per skip GEMM of the deferred-skip form (0: fused block, skip per layer)
 };
 
 struct ap_m5 {
@@ -135,7 +137,7 @@ struct UbArgs {
 };
 int launch_make_ub(const float *h, const float *pt, void *ub, int B, int C, int L, hipStream_t st);
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr, const UbArgs *ub = nullptr);
+                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr, const UbArgs *ub = nullptr, void *gout = nullptr);
 int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st);
@@ -145,10 +147,13 @@ int launch_pack_bf16(ap_ctx *ctx, hipStream_t st);
 int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca, float cb,
                              float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset, int B, int L,
                              hipStream_t st);                    // returns 1 if the shape is not served (caller: fp32 kernel)
+// `gout` non-null: the deferred-skip form -- the block writes h' and its gate output as a bf16 image [clip][L][256] to gout and
+// leaves `skip` alone; launch_skipgemm_bf16 then adds a group of layers' skip_conv outputs in one GEMM (ap_skipgemm_bf16.hip)
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr);
+                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr);   // persistent form; returns 1 if the shape is not served
+                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);   // persistent form; returns 1 if the shape is not served
+int launch_skipgemm_bf16(ap_ctx *ctx, int layer0, int nl, const void *gimg, float *skip, int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_bf16w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);   // one wave per SIMD; returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);

@@ -935,10 +935,33 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
 
 // Split-K partial sums live in a caller-owned device buffer (no allocation inside the library): without one, or with one
 // that is too small for a layer, that layer runs un-split.
-namespace { float *g_conv_ws = nullptr; size_t g_conv_ws_bytes = 0; }
+// One slot per HIP device, keyed by the device that is current when the buffer is handed over and when a layer is launched:
+// a launch on device 1 can never be pointed at device 0's buffer.  A device's buffer serves ONE stream at a time (a split-K
+// layer and its reduce own it between them): callers that drive two streams of one device give each its own call sequence
+// with ap_conv2d_set_workspace(NULL, 0) (un-split) or serialise them.
+namespace {
+constexpr int AP_MAX_DEVICES = 64;
+struct ConvWs { float *p = nullptr; size_t bytes = 0; } g_conv_ws_tab[AP_MAX_DEVICES];
+inline ConvWs conv_ws_here() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= AP_MAX_DEVICES) return ConvWs{};
+  return g_conv_ws_tab[dev];
+}
+}  // namespace
 extern "C" int ap_conv2d_set_workspace(float *ws, size_t bytes) {
-  g_conv_ws = ws;
-  g_conv_ws_bytes = ws ? bytes : 0;
+  int dev = -1;
+  AP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= AP_MAX_DEVICES) { set_error("ap_conv2d_set_workspace: device index %d out of range", dev); return -22; }
+  if (ws) {                                       // the buffer must live on the device it is registered for
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ws) != hipSuccess || at.device != dev) {
+      (void)hipGetLastError();
+      set_error("ap_conv2d_set_workspace: buffer is not memory of the current device %d", dev);
+      return -22;
+    }
+  }
+  g_conv_ws_tab[dev].p = ws;
+  g_conv_ws_tab[dev].bytes = ws ? bytes : 0;
   return 0;
 }
 
@@ -1122,8 +1145,9 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
       if (buf && p1) conv2d_f32_big2_kernel<128, 128, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else if (buf) conv2d_f32_big2_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else conv2d_f32_big2_kernel<128, 128, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
-    } else if (buf && groups == 1 && !split && !splith && tiles128 * 2 < 384 && kh * kw * (Cin / 16) >= 32 && g_conv_ws &&
-               2 * (size_t)B * Cout * a.Ho * a.Wo * sizeof(float) <= g_conv_ws_bytes) {
+    } else if (const ConvWs cws = (buf && groups == 1 && !split && !splith && tiles128 * 2 < 384 && kh * kw * (Cin / 16) >= 32)
+                                      ? conv_ws_here() : ConvWs{};
+               cws.p && 2 * (size_t)B * Cout * a.Ho * a.Wo * sizeof(float) <= cws.bytes) {
       // too few output tiles for 256 CUs and a long K (the 4 x 4 and 8 x 8 maps of the UNet: K = 2 304 .. 4 608): split-K over
       // blockIdx.z, partial sums to the caller's workspace, slices summed in order by a second small kernel (deterministic)
       const long long t64 = ((N + 63) / 64) * ((Mg + 63) / 64), t128x64 = ((N + 63) / 64) * ((Mg + 127) / 128);
@@ -1131,9 +1155,9 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
       const long long tiles = small ? t64 : t128x64;
       int S = 2;
       while (S < 8 && tiles * S < 768 && kh * kw * (Cin / 16) / (2 * S) >= 16 &&
-             (size_t)(2 * S) * B * Cout * a.Ho * a.Wo * sizeof(float) <= g_conv_ws_bytes) S *= 2;
+             (size_t)(2 * S) * B * Cout * a.Ho * a.Wo * sizeof(float) <= cws.bytes) S *= 2;
       a.splits = S;
-      a.part = g_conv_ws;
+      a.part = cws.p;
       *cls = 2;
       if (small) {
         dim3 grid((unsigned)((N + 63) / 64), (unsigned)((Mg + 63) / 64), (unsigned)S);

@@ -529,9 +529,13 @@ static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
 #endif
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st, float *aout, const UbArgs *ub) {
+                    int accumulate, int B, int L, hipStream_t st, float *aout, const UbArgs *ub, void *gout) {
   if (aout && ctx->cfg.precision != AP_PREC_F32) {
     set_error("ap_resblock_fwd_save: fp32 arithmetic only (the other modes recompute the pre-gate activations)");
+    return -22;
+  }
+  if (gout && (ctx->cfg.precision != AP_PREC_BF16 || g_force_f32)) {
+    set_error("deferred-skip form: AP_PREC_BF16 only");
     return -22;
   }
   if (ctx->cfg.precision != AP_PREC_F32 && !g_force_f32) {
@@ -545,11 +549,13 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
         }
       e0 = ctx->ev[ctx->ev_used];
       e1 = ctx->ev[ctx->ev_used + 1];
+      if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
+      ctx->ev_kind[ctx->ev_used / 2] = 0;
       ctx->ev_used += 2;
       AP_HIP(hipEventRecord(e0, st));
     }
     int rc = ctx->cfg.precision == AP_PREC_BF16
-                 ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub)
+                 ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout)
              : ctx->cfg.precision == AP_PREC_F32_SPLIT
                  ? launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st)
                  : launch_resblock_splith(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
@@ -573,6 +579,8 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
     }
     ev0 = ctx->ev[ctx->ev_used];
     ev1 = ctx->ev[ctx->ev_used + 1];
+    if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
+    ctx->ev_kind[ctx->ev_used / 2] = 0;
     ctx->ev_used += 2;
     AP_HIP(hipEventRecord(ev0, st));
   }

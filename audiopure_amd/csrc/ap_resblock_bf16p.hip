@@ -1,5 +1,5 @@
 // AP_PREC_BF16, persistent form: fused Residual_block.forward (WaveNet.py:75-97) with bf16 MFMA operands, fp32 accumulate,
-// fp32 activations in HBM -- the same arithmetic and the same packed weight images as ap_resblock_bf16.hip (outputs are
+// fp32 activations in HBM -- the same arithmetic and the same packed weight images as tools/csrc/ap_resblock_bf16.hip (outputs are
 // bit-identical: tools/cmp_bf16_kernels.py), every dilation (d <= 32 stages one 192-column window per chunk for the three taps), restructured
 // around what the round-2 ablations measured (tools/dbg_resblock_bf16.py):
 //
@@ -49,7 +49,7 @@ __device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >
 // tanh(a) sigmoid(b) = (1 - E) / ((1 + E)(1 + F)), E = e^(-2a), F = e^(-b).  a is clamped to [-16, 16] first (one v_med3;
 // tanh(+-16) rounds to +-1 in fp32, so the clamp changes no result): E stays finite, the sign comes out of 1 - E, and no
 // abs / copysign pair is needed.  F may overflow to +inf: the denominator is +inf then and the gate 0, which is the limit.
-// The same arithmetic, element for element, as gate_fast of ap_resblock_bf16.hip (the two kernels are bit-identical).
+// The same arithmetic, element for element, as gate_fast of tools/csrc/ap_resblock_bf16.hip (the two kernels are bit-identical).
 // On a pair of values: plain arithmetic as two-wide fp32 operations (v_pk_mul_f32 / v_pk_add_f32: one issue slot for two
 // gates; the file is built with -fno-slp-vectorize, so the pairing is written out), the three transcendentals per gate
 // stay scalar; the caller converts the pair to bf16 with one v_cvt_pk_bf16_f32.
@@ -223,15 +223,22 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // (tools/power_check.py), and 64 KB of extra stores per tile cost more energy than 0.3 MB less on the L2 -> CU path and the
 // pack's VALU save.  (The "no X requests / no pack" ablations that promised 13-25 % leave the X image CONSTANT: what they measure
 // is the matrix pipe's data-dependent power, not the staging -- tools/power_ablate_bf16.py.)
-template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
+// DS (round 4, "deferred skip"): the block writes h' (fp32) and the gate output g as the bf16 image GEMM2 consumes anyway --
+// [clip][sample][256 channels], 512 B per sample, lossless for the skip sum because skip_conv only ever sees bf16(g) -- and does
+// NOT run the skip half of GEMM2 or its read-modify-write of `skip`.  skipgemm_bf16_kernel (ap_skipgemm_bf16.hip) adds
+// sum_n W_skip,n g_n for a group of layers into `skip` in one K-concatenated GEMM.  h' is bit-identical to the fused form
+// (same pass-0 code); per tile and layer the block moves 131 KB in + 131 KB + 64 KB out instead of 262 + 262 KB.
+template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false, bool DS = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
     const void *__restrict__ bbase, unsigned bbytes, unsigned b1_off, unsigned b2_off,        // fp32 bias vectors (one slab)
     int L, int d, int accumulate, int ntiles, int nblk,
-    const void *__restrict__ ubin, void *__restrict__ ubout, const float *__restrict__ ptn) {   // UB: bf16 operand images in / out (out may be null), the next layer's part_t
+    const void *__restrict__ ubin, void *__restrict__ ubout, const float *__restrict__ ptn,     // UB: bf16 operand images in / out (out may be null), the next layer's part_t
+    void *__restrict__ gout) {                                                                  // DS: this layer's g image [clip][L][256] bf16
   constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
   static_assert(!UB || (WS < 0 && !M16), "UB: one staging form");
+  static_assert(!DS || (!UB && !M16), "DS: the product staging forms only");
   // cache policy: nt (aux bit 1) on the once-touched streams (the running skip rows in, both outputs out) and on the residual's
   // re-read of h (it hits what is still there and allocates nothing on a miss).  Only the tap loads and the weights allocate in
   // the XCD's L2, so h rows stay until the neighbouring tiles' taps and the residual have read them again: L2-miss reads 27.2 ->
@@ -931,10 +938,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     load_pre(hrs, I3{});
     __builtin_amdgcn_sched_barrier(0);
     gate_ct(I2{});
-    load_pre1(I0{});
+    if constexpr (!DS) load_pre1(I0{});
     __builtin_amdgcn_sched_barrier(0);
     gate_ct(I3{});
-    load_pre1(I1{});
+    if constexpr (!DS) load_pre1(I1{});
     fetch_bias(I0{});
     load_a4(p1, 4);
     __builtin_amdgcn_sched_barrier(0);
@@ -982,10 +989,10 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll 1
       for (int ks = 0; ks < NKS; ks += 8) {
         step(p0[0], ba, bb, ks + 0); step(p0[1], bb, ba, ks + 1); step(p0[2], ba, bb, ks + 2); step(p0[3], bb, ba, ks + 3);
-        load_a4(p0, pass * NKS + ks + 8);
+        if (!DS || ks + 8 < NKS) load_a4(p0, pass * NKS + ks + 8);      // (DS: one pass -- nothing to prefetch past its last k-steps)
         __builtin_amdgcn_sched_barrier(0);
         step(p1[0], ba, bb, ks + 4); step(p1[1], bb, ba, ks + 5); step(p1[2], ba, bb, ks + 6); step(p1[3], bb, ba, ks + 7);
-        load_a4(p1, pass * NKS + ks + 12);
+        if (!DS || ks + 12 < NKS) load_a4(p1, pass * NKS + ks + 12);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       constexpr bool UBW = UB && decltype(first_tag)::value;     // pass 0 of the chain's form also writes the next layer's operand image
 #pragma unroll
       for (int ct = 0; ct < 4; ct++) {
-        if constexpr (decltype(first_tag)::value) {             // pass 0: the h-patch registers of tiles 0, 1 are free again
+        if constexpr (decltype(first_tag)::value && !DS) {      // pass 0: the h-patch registers of tiles 0, 1 are free again
           if (ct == 2) load_pre1(I2{});
           if (ct == 3) load_pre1(I3{});
         }
@@ -1056,7 +1063,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       }
     };
 
-    {
+    if constexpr (!DS) {
       f32x16 ac[4];
       gemm2_loop(ac, 0);
       mark(28);
@@ -1077,7 +1084,40 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     x_geom(t0_nxt, xvoff, keep);
     issue_x(AP_XRS, xvoff, 0);
     __builtin_amdgcn_sched_barrier(0);
-    {
+    if constexpr (DS) {
+      // the ONE pass of this form (res_conv rows -> h'), in the place and with the request order the fused form gives its
+      // last pass: the next tile's first chunk is in flight under the MFMAs, its pack and first fragments go out before the
+      // stores, the stores drain behind the next tile's GEMM1
+      f32x16 ac[4];
+      gemm2_loop(ac, 0);
+      mark(30);
+      tile_head();
+      mark(31);
+      __builtin_amdgcn_sched_barrier(0);
+      epilogue(ac, pre, ors, RS, std::false_type{});
+      // g image -> HBM: 128 columns x 512 B, one 16-byte piece per lane and step (a wave moves two whole columns per step:
+      // 1 KB contiguous on both sides; the padded 528-B LDS rows keep the 16-lane groups of ds_read_b128 on distinct banks)
+      {
+        int ln;                                                  // (lane id read here, not kept: see x_geom)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const uint64_t gb_ = (uint64_t)gout + (uint64_t)b_cur * ((uint64_t)L * 512u);
+        const uint32_t glo = __builtin_amdgcn_readfirstlane((uint32_t)gb_);
+        const uint32_t ghi = __builtin_amdgcn_readfirstlane((uint32_t)(gb_ >> 32));
+        const __amdgpu_buffer_rsrc_t grs =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)ghi << 32) | glo), 0, (int)((unsigned)L * 512u), 0x00020000);
+        const int colw = 2 * wave + (ln >> 5), q = ln & 31;
+        const unsigned char *src = lds + GOFF + colw * (GS_ * 2) + q * 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const u32x4 v = *reinterpret_cast<const u32x4 *>(src + 16 * i * (GS_ * 2));
+          const int t = t0 + colw + 16 * i;
+          const unsigned off = t < L ? (unsigned)t * 512u + (unsigned)q * 16u : 0x80000000u;   // outside the clip: dropped
+          if constexpr (DBG & 256) asm volatile("" ::"v"(v));
+          else __builtin_amdgcn_raw_buffer_store_b128(v, grs, off, 0, NTS);
+        }
+      }
+      mark(32);
+    } else {
       f32x16 ac[4];
       gemm2_loop(ac, 1);
       mark(30);
@@ -1106,7 +1146,7 @@ namespace ap {
 
 // -> 0 launched, 1 shape not served by this kernel (caller falls back to the per-tile kernel)
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                          int B, int L, hipStream_t st, const UbArgs *ub) {
+                          int B, int L, hipStream_t st, const UbArgs *ub, void *gout) {
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   if (C != 256 || S != 256 || L < 1) return 1;
@@ -1114,13 +1154,15 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   // staging form: one window for the three taps where they overlap (d <= 32), else three tap loads
   const int ws = d == 1 ? 1 : d == 2 ? 2 : (d <= 32 && d % 4 == 0) ? 0 : d < 4 ? -2 : -1;
   if (ws == -2) return 1;                                        // (d = 3: no such dilation in a power-of-two cycle)
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
-      n = 256;
-    n_cu = n;
+  static int n_cu_of[64] = {0};                                  // CU count per HIP device (the grid is one workgroup per CU)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (n_cu_of[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    n_cu_of[dev] = n;
   }
+  const int n_cu = n_cu_of[dev];
   const int ntiles = (L + PT_ - 1) / PT_;
   const int nblk = B * ntiles;
   int grid = nblk < n_cu ? nblk : n_cu;
@@ -1138,22 +1180,40 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   const unsigned bbytes = (unsigned)((bhi - blo + (size_t)ctx->NL * 2 * C) * 4);
 #define AP_P_LAUNCH(D)                                                                                                        \
   resblock_bf16p_kernel<D><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, \
-                                                           b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr)
+                                                           b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr, nullptr)
 #define AP_P_LAUNCH_WIN(D, W)                                                                                                 \
   resblock_bf16p_kernel<D, W><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,  \
-                                                              b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr)
+                                                              b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr, nullptr)
 #define AP_P_LAUNCH_RAG(W)                                                                                                    \
   resblock_bf16p_kernel<0, W, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes, \
-                                                                    b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr)
+                                                                    b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr, nullptr)
+  if (gout) {                                                    // deferred-skip form: h' + the bf16 g image, no skip GEMM in the block
+    if ((size_t)L * 512 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16: clip too long for the bf16 g image"); return -22; }
+#define AP_P_LAUNCH_DS(W, R)                                                                                                   \
+  resblock_bf16p_kernel<0, W, R, false, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, nullptr, wlo, wbytes, w1_off, w2_off, blo, \
+                                                                                     bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr,   \
+                                                                                     nullptr, nullptr, gout)
+    if (rag) {
+      if (ws == 1) AP_P_LAUNCH_DS(1, true);
+      else if (ws == 2) AP_P_LAUNCH_DS(2, true);
+      else AP_P_LAUNCH_DS(-1, true);
+    } else if (ws == 0) AP_P_LAUNCH_DS(0, false);
+    else if (ws == 1) AP_P_LAUNCH_DS(1, false);
+    else if (ws == 2) AP_P_LAUNCH_DS(2, false);
+    else AP_P_LAUNCH_DS(-1, false);
+#undef AP_P_LAUNCH_DS
+    AP_HIP(hipGetLastError());
+    return 0;
+  }
 #ifdef AP_TOOLS
   if (ub) {                                                      // the operand-image experiment: images in / out, one staging form for every d
     if ((size_t)C * (size_t)L * 2 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16: clip too long for the bf16 operand image"); return -22; }
     if (rag)
       resblock_bf16p_kernel<0, -1, true, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,
-                                                                                      b1_off, b2_off, L, d, accumulate, ntiles, nblk, ub->in, ub->out, ub->pt_next);
+                                                                                      b1_off, b2_off, L, d, accumulate, ntiles, nblk, ub->in, ub->out, ub->pt_next, nullptr);
     else
       resblock_bf16p_kernel<0, -1, false, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1_off, w2_off, blo, bbytes,
-                                                                                       b1_off, b2_off, L, d, accumulate, ntiles, nblk, ub->in, ub->out, ub->pt_next);
+                                                                                       b1_off, b2_off, L, d, accumulate, ntiles, nblk, ub->in, ub->out, ub->pt_next, nullptr);
     AP_HIP(hipGetLastError());
     return 0;
   }
@@ -1172,7 +1232,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   if ((g_dbg_bf16 & 0x200000) && ctx->w1q_bf) {                  // tools bit 0x200000: GEMM1 on v_mfma_f32_16x16x32_bf16 (exact; A/B)
     const unsigned w1q_off = (unsigned)((const char *)ctx->w1q_bf - wlo + layer * n1 * 2);
     resblock_bf16p_kernel<0, -1, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, skip, wlo, wbytes, w1q_off, w2_off, blo,
-                                                                            bbytes, b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr);
+                                                                            bbytes, b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr, nullptr);
   } else
   if (g_dbg_bf16 & 0x100000) AP_P_LAUNCH(0x100000);             // timing only: v_mfma_f32_16x16x32_bf16 pairs in place of 32x32x16
   else if ((g_dbg_bf16 & 0x7000000) == 0x1000000) AP_P_LAUNCH(0x1000000);   // store cache policies (exact)
@@ -1243,14 +1303,14 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 #ifndef AP_TOOLS
 // AP_PREC_BF16 dispatch of the product library: the persistent kernel serves every shape of the supported configuration
 // (C = S = 256; any dilation of a power-of-two cycle, any clip length).  The one-tile-per-workgroup kernel of round 1
-// (ap_resblock_bf16.hip) is compiled into the tools library only, as the A/B baseline of tools/cmp_bf16_kernels.py.
+// (tools/csrc/ap_resblock_bf16.hip) is compiled into the tools library only, as the A/B baseline of tools/cmp_bf16_kernels.py.
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                         int B, int L, hipStream_t st, const UbArgs *ub) {
+                         int B, int L, hipStream_t st, const UbArgs *ub, void *gout) {
   if (ctx->C != 256 || ctx->S != 256) {
     set_error("AP_PREC_BF16 is built for res_channels = skip_channels = 256 only (got %d / %d)", ctx->C, ctx->S);
     return -22;
   }
-  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub);
+  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout);
   if (rc == 1) {
     set_error("AP_PREC_BF16: shape not served (layer %d, L = %d)", layer, L);
     return -22;

@@ -9,7 +9,7 @@
 // 6x longer accumulation chain; tests/test_gpu_parity.py holds both kernels to the same tolerances).
 // 6 bf16 MFMAs = 6/16 of the fp32 instruction's time.
 //
-// Structure follows ap_resblock_bf16.hip (128-sample tiles, 8 waves x (64 rows x 128 columns), bf16 [column][k] LDS
+// Structure follows tools/csrc/ap_resblock_bf16.hip (128-sample tiles, 8 waves x (64 rows x 128 columns), bf16 [column][k] LDS
 // images, 16-B read-modify-write through a wave-private patch) with three images per operand; chunks are 16 channels
 // (48 K rows) so two X buffers x three splits fit, and gate + GEMM2 run per 64-column half so the three g images do.
 #include <type_traits>

@@ -85,6 +85,12 @@ class NativeEngine:
         self.ws = None
         self.max_chunk = 512
         self.loaded_key = None
+        # AP_PREC_BF16, deferred-skip form (include/audiopure.h, ap_ctx_set_skip_group): layers per skip GEMM.  None = chosen per
+        # (B, L) from the memory that is free (each layer of a group keeps a [B][L][C] bf16 image: 8.2 MB per clip-second);
+        # 0 = the fused block with one read-modify-write of skip per layer.
+        self.skip_group = None
+        self._group_of = {}
+        self._ds_ok = (precision == N.AP_PREC_BF16 and cfg["res_channels"] == 256 and cfg["skip_channels"] == 256)
 
     def __del__(self):
         try:
@@ -110,7 +116,37 @@ class NativeEngine:
         a, b = N.farr(betas.detach().cpu().float().tolist()), N.farr(ac.detach().cpu().float().tolist())
         N.check(self.lib.ap_ctx_set_sde_schedule(self.ctx, a, b, len(a)), "ap_ctx_set_sde_schedule")
 
+    SKIP_GROUPS = (36, 18, 12, 9, 6, 4, 3, 2)      # candidates, largest first
+    SKIP_WS_FRACTION = 0.55                          # of the device memory that is free (the current workspace counted as free)
+
+    def _pick_skip_group(self, B: int, L: int, device) -> int:
+        if not self._ds_ok:
+            return 0
+        if self.skip_group is not None:
+            return int(self.skip_group)
+        key = (B, L, device)
+        if key not in self._group_of:
+            NL = self.cfg.num_res_layers
+            try:
+                free, _ = torch.cuda.mem_get_info(device)
+                free += max(torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device), 0)
+            except (RuntimeError, AssertionError):
+                free = 0
+            free += self.ws.numel() if self.ws is not None and self.ws.device == device else 0
+            N.check(self.lib.ap_ctx_set_skip_group(self.ctx, 0), "ap_ctx_set_skip_group")
+            base = self.lib.ap_workspace_bytes(self.ctx, B, L)
+            slot = B * L * self.cfg.res_channels * 2
+            pick = 0
+            for g in self.SKIP_GROUPS:
+                if g <= NL and base + g * slot <= self.SKIP_WS_FRACTION * free:
+                    pick = g
+                    break
+            self._group_of[key] = pick
+        return self._group_of[key]
+
     def workspace(self, B: int, L: int, device) -> torch.Tensor:
+        if self._ds_ok:                              # the context's group size and the workspace handed over go together
+            N.check(self.lib.ap_ctx_set_skip_group(self.ctx, self._pick_skip_group(B, L, device)), "ap_ctx_set_skip_group")
         need = self.lib.ap_workspace_bytes(self.ctx, B, L)
         if self.ws is None or self.ws.numel() < need or self.ws.device != device:
             self.ws = None

@@ -90,6 +90,7 @@ class EpsGrad:
         elif self.net._precision == N.AP_PREC_F32_SPLIT_F16:
             flags |= 0x400                                       # AP_CONV_SPLIT_F16
         fl = flags | _F1D | ((dil << 16) if dil > 1 else 0)
+        N.use_conv_workspace(x.device)                           # short clips meet the split-K condition: this device's buffer
         N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(packed), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, 1, L, Cout, 1, kw, 1,
                                   pad, 1, fl, Cin, 0, N.stream()), "ap_conv2d_fwd")
 
@@ -202,6 +203,9 @@ def _chain_budget(device) -> int:
     samples, sample_step > 1 -- start one after the other, each seeing what the earlier ones hold)."""
     try:
         free, _ = torch.cuda.mem_get_info(device)
+        # blocks torch's caching allocator holds but has free are as reusable as driver-free memory: after the first chain of a
+        # PGD loop tens of GB sit there, and counting only the driver's figure would shrink every later chain's budget
+        free += max(torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device), 0)
     except (RuntimeError, AssertionError):
         return SAVE_BUDGET_BYTES
     return int(min(SAVE_BUDGET_BYTES, SAVE_FREE_FRACTION * free))
@@ -282,8 +286,10 @@ class _ChainFn(torch.autograd.Function):
                 (t, ca, cb, cs, draw), xt = ctx.steps[k], ctx.xs[k]
                 saved = ctx.saves[k]
                 ctx.saves[k] = None
-                if saved is None:
-                    _, saved = ctx.grad.forward_save(xt, t)      # over budget in the forward pass: recompute this link
+                if saved is None:                                # over budget in the forward pass: recompute this link -- with the
+                    sizes = getattr(ctx.grad, "saved_bytes", None)   # pre-gate activations only if they fit what is free NOW
+                    lean_only = sizes is not None and sizes(xt, True) > _chain_budget(xt.device)
+                    _, saved = ctx.grad.forward_save(xt, t, acts=False) if lean_only else ctx.grad.forward_save(xt, t)
                 g = _axpby(g, ctx.grad.backward(saved, g), ca, cb)
                 del saved
             if ctx.qa != 1.0:

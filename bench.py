@@ -85,11 +85,29 @@ class PowerSampler:
     power cap and the firmware lowers the clock under them, and the line should say so itself.  None when
     rocm-smi is missing or prints nothing usable."""
 
-    def __init__(self, device_index=0, enabled=True):
+    def __init__(self, device_index=0, enabled=True, pci_bus_id=None):
+        """`device_index` is torch's LOGICAL index; rocm-smi numbers PHYSICAL boards.  With `pci_bus_id` (device_descriptor) the
+        board is looked up in `rocm-smi --showbus`, so under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES the sampled board is the
+        one the kernels run on; the result says which index was polled and how it was found."""
         import shutil
         self.exe = (shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)) if enabled else None
-        self.dev = device_index
+        self.dev, self.dev_source = device_index, "logical index (no PCI match)"
+        if self.exe and pci_bus_id:
+            self._resolve(pci_bus_id)
         self.samples, self.stop, self.thread = [], False, None
+
+    def _resolve(self, pci_bus_id):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run([self.exe, "--showbus"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            return
+        want = pci_bus_id.lower()
+        for m in re.finditer(r"GPU\[(\d+)\]\s*:\s*PCI Bus:\s*([0-9a-fA-F:.]+)", out):
+            if m.group(2).lower().startswith(want):
+                self.dev, self.dev_source = int(m.group(1)), f"rocm-smi --showbus match of {pci_bus_id}"
+                return
 
     def _read(self, extra=()):
         import re
@@ -130,6 +148,7 @@ class PowerSampler:
         cap = self._read(("--showmaxpower",))[2]
         return {"board_W_mean": round(sum(ws) / len(ws), 1), "board_W_max": round(max(ws), 1), "cap_W": cap,
                 "sclk_MHz_mean": round(sum(cs) / len(cs)), "sclk_MHz_min": min(cs), "samples": len(ws),
+                "smi_index": self.dev, "smi_index_source": self.dev_source,
                 "source": "rocm-smi --showpower --showclocks polled every 0.5 s over the timed region"}
 
 
@@ -269,7 +288,7 @@ def bench_config4(dev, steps, B=256, n=5):
         y = system(x, True)                                             # warm-up: lowering, weight packing
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with PowerSampler(dev.index or 0) as ps:
+        with PowerSampler(dev.index or 0, pci_bus_id=device_descriptor(torch, dev.index or 0).get("pci_bus_id")) as ps:
             t0 = time.perf_counter()
             e0.record()
             for _ in range(steps):
@@ -343,6 +362,8 @@ def main():
                          "whose activations (3 x 65.5 MB per clip) stay resident in the 256 MB Infinity Cache")
     args = ap.parse_args()
 
+    if args.chunk > 0 and args.batch % args.chunk:
+        raise SystemExit("--chunk must divide --batch (the roofline object prices every launch at `chunk` clips)")
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "RANK" not in os.environ:
         # Children, not exec: nothing in this process has touched a GPU, and it only relays the ranks' exit code.
@@ -421,7 +442,7 @@ def main():
                 step()
             N.check(eng.lib.ap_profile_enable(eng.ctx, 1))
             fence()
-            with PowerSampler(local, enabled=rank == 0) as ps:    # (rank 0's GPU only: one host-side poll per job)
+            with PowerSampler(local, enabled=rank == 0, pci_bus_id=device_descriptor(torch, local).get("pci_bus_id")) as ps:    # (rank 0's GPU only)
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     lp = step()

@@ -46,7 +46,9 @@ typedef struct ap_m5 ap_m5;
 /* arithmetic mode of the two residual-block GEMMs */
 enum {
   AP_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate   */
-  AP_PREC_BF16 = 1,  /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM */
+  AP_PREC_BF16 = 1,  /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM.  Built for the shipped
+                        configuration only: res_channels == skip_channels == 256 (any dilation of a power-of-two cycle,
+                        any clip length); other shapes return -EINVAL at the first launch (ap_last_error says which) */
   AP_PREC_F32_SPLIT = 2, /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
                             each product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-class results (dropped
                             terms < 2^-23 of a product) at 6/16 of the fp32 matrix instruction's time; C = 256 */
@@ -122,6 +124,9 @@ int ap_ctx_get_schedule(ap_ctx *ctx, int which, float *out_host, int n);
  * and the number of launches since ap_profile_enable, and resets the counter.  Not graph-capturable while on. */
 int ap_profile_enable(ap_ctx *ctx, int enable);
 int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches);
+/* The same reading split by kernel: [0] residual-block launches, [1] skip-GEMM launches of the deferred-skip form (whose time
+ * ap_profile_read folds into total_ms while counting only the block launches, so "ms per layer" stays comparable). */
+int ap_profile_read_split(ap_ctx *ctx, double *ms_by_kind, int64_t *launches_by_kind);
 
 /* The same hook for the conv-as-GEMM family (BASELINE configs[4]; replaces nothing in the reference -- it times the kernels
  * that stand in for nn.Conv2d / nn.Conv1d / nn.Linear of improved_diffusion/unet.py:462-491 and models/resnext.py:67-142):
@@ -130,7 +135,10 @@ int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches);
  * 2 big2<128,64>, 3 split-operand kernels, 4 conv2d_f32_big, 5 generic -- into caller arrays of n_classes >= 6, and resets. */
 /* Caller-owned device buffer for the split-K partial sums of low-resolution conv layers (K sliced over workgroups when a layer
  * has too few output tiles for the chip; slices are summed in order by a second kernel: deterministic).  NULL / 0 disables
- * split-K; a layer whose partial sums do not fit runs un-split.  The library allocates nothing itself. */
+ * split-K; a layer whose partial sums do not fit runs un-split.  The library allocates nothing itself.
+ * The buffer is registered for the HIP device that is CURRENT at the call (it must be that device's memory, else -EINVAL) and a
+ * launch only ever uses the buffer of the device it is issued on; one buffer serves one stream at a time (a split-K layer
+ * and its reduce own it between them). */
 int ap_conv2d_set_workspace(float *ws, size_t bytes);
 int ap_conv_profile_enable(int enable);
 int ap_conv_profile_read(double *ms_by_class, double *flop_by_class, int64_t *launches_by_class, int n_classes);
@@ -158,6 +166,24 @@ int ap_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L, void *stre
  * h_out must not alias h_in (taps at t +- d read other tiles). */
 int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer,
                     float *h_out, float *skip, int accumulate_skip, int B, int L, void *stream);
+
+/* Deferred-skip form of the block (AP_PREC_BF16, res = skip = 256 channels; round 4).  WaveNet.py:90-97,131-135: skip_conv only
+ * ever sees bf16(g) in this mode, so the block can hand g on as that bf16 image and the sum over layers `skip += skip_n`
+ * (:131-133) can be taken inside one K-concatenated GEMM per group of layers instead of one read-modify-write of the fp32
+ * skip tensor per layer.
+ *   ap_resblock_fwd_gate: the block of ap_resblock_fwd without skip_conv: writes h_out (bit-identical to ap_resblock_fwd's) and
+ *                         g_image [B][L][C] bf16 (512 bytes per sample, channels contiguous); `skip` is not touched.
+ *   ap_skip_gemm:         skip (+)= sum_{n = layer0 .. layer0 + n_layers - 1} (W_skip,n g_n + b_skip,n) with
+ *                         g_images [n_layers][B][L][C] bf16 (slot n - layer0); accumulate_skip = 0 writes skip.
+ *   ap_ctx_set_skip_group(G): G > 0 makes ap_eps_fwd / ap_purify_* run this form with groups of G layers (the workspace grows
+ *                         by G x B x L x C x 2 bytes: ap_workspace_bytes follows); 0 (default) = the fused block per layer.
+ * Results: h identical bit for bit; skip differs from the per-layer form by fp32 summation order only (the bf16 products are
+ * the same; a group's K = G x 256 is accumulated in the matrix pipe's fp32 accumulators). */
+int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
+                         void *g_image, int B, int L, void *stream);
+int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, float *skip, int accumulate_skip,
+                 int B, int L, void *stream);
+int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group);
 
 /* ap_resblock_fwd_save: ap_resblock_fwd that also writes the pre-gate activations y = DilConv(u) + b (WaveNet.py:87) to
  * pre_gate [B][2C][L] (rows 0..C-1 the tanh half, C..2C-1 the sigmoid half): what the backward of :90 needs, kept by the

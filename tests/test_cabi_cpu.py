@@ -79,6 +79,31 @@ def test_unloaded_context_refuses_compute(lib):
     assert lib.ap_melspec_db(None, None, 32, 0, 1, 16000, None) == -22
 
 
+def test_skip_group_option_is_validated_and_sizes_the_workspace(lib):
+    """ap_ctx_set_skip_group (deferred-skip form of the bf16 block): only on a bf16 context with 256 channels, group size in
+    [0, num_res_layers]; ap_workspace_bytes grows by exactly G images of [B][L][C] bf16."""
+    h = C.c_void_p()
+    cfg = _cfg(256, 256, prec=N.AP_PREC_BF16)
+    N.check(lib.ap_ctx_create(C.byref(cfg), C.byref(h)))
+    base = lib.ap_workspace_bytes(h, 3, 1001)
+    for G in (1, 6, 36):
+        N.check(lib.ap_ctx_set_skip_group(h, G))
+        grown = lib.ap_workspace_bytes(h, 3, 1001) - base
+        assert G * 3 * 1001 * 256 * 2 <= grown < G * 3 * 1001 * 256 * 2 + 256
+    N.check(lib.ap_ctx_set_skip_group(h, 0))
+    assert lib.ap_workspace_bytes(h, 3, 1001) == base
+    assert lib.ap_ctx_set_skip_group(h, 37) == -22 and lib.ap_ctx_set_skip_group(h, -1) == -22
+    N.check(lib.ap_ctx_destroy(h))
+    f32 = C.c_void_p()
+    cfg = _cfg(256, 256)
+    N.check(lib.ap_ctx_create(C.byref(cfg), C.byref(f32)))
+    assert lib.ap_ctx_set_skip_group(f32, 6) == -22 and b"AP_PREC_BF16" in lib.ap_last_error()
+    N.check(lib.ap_ctx_set_skip_group(f32, 0))
+    assert lib.ap_resblock_fwd_gate(f32, 0, None, None, None, None, 1, 100, None) == -22
+    assert lib.ap_skip_gemm(f32, 0, 1, None, None, 0, 1, 100, None) == -22
+    N.check(lib.ap_ctx_destroy(f32))
+
+
 def test_cpu_tensors_are_rejected():
     import torch
     with pytest.raises(N.NativeError):

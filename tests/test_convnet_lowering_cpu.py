@@ -97,6 +97,28 @@ def test_restated_models_have_reference_state_dict_keys():
     assert list(vgg19_bn(10, 1).state_dict().keys()) == list(g["vgg19_bn/keys"])
     assert list(CifarResNeXt(10).state_dict().keys()) == list(g["resnext29_8_64/keys"])
     assert sum(p.numel() for p in CifarResNeXt(10).parameters()) == 34425546
+    from synth_convnets import FAMILIES
+    for name, make in FAMILIES.items():                                          # all six of models/__init__.py:8-45
+        assert set(make().state_dict()) == set(str(k) for k in g[f"{name}/keys"]), name
+
+
+@pytest.mark.parametrize("name", ["resnet50", "wideresnet28_10", "dpn92", "densenet_bc_100_12"])
+def test_restated_families_reproduce_reference_logits_and_lower(name):
+    """The containers the GPU tests run (tools/synth_convnets.py) ARE the reference's networks: with weights keyed on the
+    state-dict names they reproduce logits of the reference's own classes (golden_convnets_v1.npz) on CPU, and their
+    lowered plan replays to the same logits through the plan oracle."""
+    import os
+    from audiopure_amd import synth
+    from synth_convnets import FAMILIES
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_convnets_v1.npz"))
+    m = synth_init(FAMILIES[name](), 0)
+    x = torch.from_numpy(synth.uniform("mel", (2, 1, 32, 32), 3, -2.0, 2.0))
+    with torch.no_grad():
+        y = m(x)
+    gold = g[f"{name}/logits"]
+    assert np.abs(y.numpy() - gold).max() <= 1e-6 * np.abs(gold).max()
+    yp = run_plan_torch(lower(m), x)
+    assert float((y - yp).abs().max() / y.abs().max()) < 1e-4
 
 
 def test_mel_front_end_with_other_band_or_framing_is_left_alone():

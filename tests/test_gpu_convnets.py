@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from audiopure_amd import synth
-from synth_convnets import CifarResNeXt, synth_init, vgg19_bn
+from synth_convnets import FAMILIES, CifarResNeXt, synth_init, vgg19_bn
 from audiopure_amd.convnet import NativeConvNet
 from conftest import rel_err
 
@@ -30,9 +30,11 @@ def _x(B=2):
     return torch.from_numpy(synth.uniform("mel", (B, 1, 32, 32), 3, -2.0, 2.0))
 
 
-@pytest.mark.parametrize("name,make", [("vgg19_bn", lambda: vgg19_bn(10, 1)), ("resnext29_8_64", lambda: CifarResNeXt(10))])
-def test_full_models_match_reference_golden(dev, gold, name, make):
-    m = synth_init(make(), 0)
+@pytest.mark.parametrize("name", sorted(FAMILIES))
+def test_full_models_match_reference_golden(dev, gold, name):
+    """All six families of models/__init__.py:8-45 on the HIP executor against logits of the REFERENCE's own classes."""
+    m = synth_init(FAMILIES[name](), 0)
+    assert set(m.state_dict()) == set(str(k) for k in gold[f"{name}/keys"])
     net = NativeConvNet(m).eval()
     y = net(_x().to(dev)).cpu().numpy()
     assert y.shape == (2, 10)

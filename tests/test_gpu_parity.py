@@ -455,6 +455,85 @@ def test_bf16_resblock_matches_bf16_emulating_oracle(dev, L, layer):
     # and the distance to the exact fp32 block is the bf16 operand rounding, reported tolerance 3e-2 of max
     assert rel_err(hout.cpu().numpy(), h_f.numpy()) < 3e-2
     assert rel_err((sk.cpu() - skip0).numpy(), s_f.numpy()) < 3e-2
+    # deferred-skip form (round 4; include/audiopure.h): the block without skip_conv + the skip GEMM over its bf16 g image.
+    # h' is the same pass of the same kernel: bit for bit.  A one-layer group accumulates in the fused form's order: bit for bit.
+    hout2 = torch.empty_like(hd)
+    gimg = torch.empty((B, L, C_), dtype=torch.bfloat16, device=dev)
+    sk2 = skip0.to(dev).clone()
+    N.check(eng.lib.ap_resblock_fwd_gate(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout2), gimg.data_ptr(), B, L, N.stream()))
+    N.check(eng.lib.ap_skip_gemm(eng.ctx, layer, 1, gimg.data_ptr(), N.ptr(sk2), 1, B, L, N.stream()))
+    assert torch.equal(hout2, hout)
+    assert torch.equal(sk2, sk)
+    sk3 = torch.full_like(sk2, 3.0)                              # accumulate_skip = 0 overwrites
+    N.check(eng.lib.ap_skip_gemm(eng.ctx, layer, 1, gimg.data_ptr(), N.ptr(sk3), 0, B, L, N.stream()))
+    assert rel_err(sk3.cpu().numpy(), s_q.numpy()) < 4e-3
+
+
+@pytest.mark.parametrize("L,layer0,nl", [(16000, 0, 12), (4001, 3, 5), (1002, 9, 3), (130, 10, 2)])
+def test_bf16_skip_gemm_over_a_group_of_layers_matches_the_oracle_sum(dev, L, layer0, nl):
+    """WaveNet.py:131-133 `skip += skip_n` taken inside one K-concatenated GEMM: a group of consecutive layers run through
+    ap_resblock_fwd_gate (each writing its bf16 g image) and ONE ap_skip_gemm, against the bf16-emulating oracle's sum of
+    the per-layer skip outputs and against the fused per-layer kernel (fp32 summation order only: 5e-6)."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    net.set_precision("bf16")
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    B, C_ = 2, 256
+    h = torch.from_numpy(synth.uniform(f"hg/{L}", (B, C_, L), 1, -1.5, 1.5))
+    base = torch.from_numpy(synth.uniform(f"sg/{L}", (B, C_, L), 1, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    s_sum, hq, pts = torch.zeros_like(h), h.clone(), []
+    with torch.no_grad():
+        for n in range(layer0, layer0 + nl):
+            p = f"residual_layer.residual_blocks.{n}"
+            pts.append(torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1))
+            hq, s_n = O.residual_block(w, n, 2 ** (n % 12), hq, emb, bf16_operands=True)
+            s_sum += s_n
+    gimg = torch.empty((nl, B, L, C_), dtype=torch.bfloat16, device=dev)
+    hin, sk_fused = h.to(dev), base.to(dev).clone()
+    for i, n in enumerate(range(layer0, layer0 + nl)):
+        ho, ho2 = torch.empty_like(hin), torch.empty_like(hin)
+        pt = pts[i].to(dev).contiguous()
+        N.check(eng.lib.ap_resblock_fwd(eng.ctx, n, N.ptr(hin), N.ptr(pt), N.ptr(ho), N.ptr(sk_fused), 1, B, L, N.stream()))
+        N.check(eng.lib.ap_resblock_fwd_gate(eng.ctx, n, N.ptr(hin), N.ptr(pt), N.ptr(ho2), gimg[i].data_ptr(), B, L, N.stream()))
+        assert torch.equal(ho, ho2)
+        hin = ho
+    sk = base.to(dev).clone()
+    N.check(eng.lib.ap_skip_gemm(eng.ctx, layer0, nl, gimg.data_ptr(), N.ptr(sk), 1, B, L, N.stream()))
+    got = (sk.cpu() - base).numpy()
+    # (the oracle's h runs ahead through nl layers of bf16 rounding-boundary flips: a looser bar than one layer's 4e-3)
+    assert rel_err(got, s_sum.numpy()) < 4e-3 * max(1.0, nl ** 0.5)
+    assert rel_err(got, (sk_fused.cpu() - base).numpy()) < 5e-6
+
+
+@pytest.mark.parametrize("L", [16000, 1001])
+def test_bf16_eps_is_the_same_for_every_skip_group_size(dev, L):
+    """ap_ctx_set_skip_group: groups of G layers per skip GEMM (G = 1 accumulates in the fused form's order: bit-identical eps;
+    larger groups change the fp32 summation order of skip only, which final_conv's bf16 operand rounding turns into isolated
+    rounding-boundary flips: 3e-3 of max|eps|, inside the mode's 1e-2 per evaluation), uneven last group included."""
+    cfg = synth.mini_wavenet_config(256, 14, 12)
+    net, _ = _net(cfg, dev, seed=8)
+    net.set_precision("bf16")
+    eng = net.engine()
+    x = torch.from_numpy(synth.waveforms(3, L, seed=L)).to(dev)
+    try:
+        eng.skip_group = 0
+        ref = net.eps(x, 7.0)
+        eng.skip_group = 1
+        assert torch.equal(net.eps(x, 7.0), ref)
+        for G in (4, 7, 14):
+            eng.skip_group = G
+            got = net.eps(x, 7.0)
+            assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 3e-3, G
+        eng.skip_group = None                                    # the engine's own choice (memory permitting: the largest group)
+        got = net.eps(x, 7.0)
+        assert eng._pick_skip_group(3, L, x.device) > 0
+        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 3e-3
+    finally:
+        eng.skip_group = None
 
 
 TOL_BF16_CHAIN = 5e-3          # bf16-mode chain vs the bf16-emulating chain oracle (same operand roundings, fp32 elsewhere)
@@ -596,9 +675,10 @@ def test_split_full_chain_matches_reference_golden_at_the_fp32_tolerance(golden,
     dw.set_noise_source([torch.from_numpy(synth.noise(d, 2, 16000, seed=1234)) for d in range(5)])
     xp = dw(x0)
     assert rel_err(xp.cpu().numpy(), golden["full/ddpm_n5/x"]) < TOL_CHAIN
-    assert rel_err(dw.one_shot_denoise(x0).cpu().numpy(), golden["full/one_shot_t5"] if "full/one_shot_t5" in golden
-                   else DiffWave(model=net.set_precision("f32"), diffusion_hyperparams=dh,
-                                 reverse_timestep=5).one_shot_denoise(x0).cpu().numpy()) < TOL_EVAL
+    # one-shot denoise against the reference's own vector (t* = 25 is what make_golden.py holds; a missing key is a KeyError,
+    # never a HIP-vs-HIP comparison)
+    dw25 = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=25)
+    assert rel_err(dw25.one_shot_denoise(x0).cpu().numpy(), golden["full/one_shot_t25"]) < TOL_EVAL
 
 
 @pytest.mark.parametrize("L", [16000, 2048, 1500, 132])
@@ -610,7 +690,8 @@ def test_bf16_chain_staging_from_the_previous_epilogue_is_bit_identical(dev, L):
     cfg = synth.mini_wavenet_config(256, 14, 12)
     net, _ = _net(cfg, dev, seed=8)
     net.set_precision("bf16")
-    x = torch.from_numpy(synth.waveforms(3, L, seed=L)).to(dev)
+    net.engine().skip_group = 0                                  # the fused block per layer on both sides (the deferred-skip form
+    x = torch.from_numpy(synth.waveforms(3, L, seed=L)).to(dev)  # sums skip in another order: its own tests above)
     eps_chain = net.eps(x, 7.0)
     eps_layers, _ = EpsGrad(net).forward_save(x, 7.0)
     assert torch.equal(eps_chain, eps_layers)
@@ -682,6 +763,32 @@ def test_c_entry_points_match_python_chains(mini, dh, dev):
     # sample_step = 2 concatenates along the batch axis like the reference (diffwave_sde.py:212)
     args.sample_step = 2
     assert RevDiffWave.from_model(dw, args)(x0).shape[0] == 2 * B
+
+
+def test_c_entry_points_meet_reference_golden_directly(golden, mini, dh, dev):
+    """ap_purify_ddpm and ap_one_shot_denoise called through ctypes -- no Python chain class in between -- against vectors
+    of the REFERENCE's DiffWave (tests/golden/make_golden.py): mini net DDPM n = 3 with the injected noise list
+    (diffwave_ddpm.py:36-104,143-164) and the shipped net's one_shot_denoise at t* = 25 (diffwave_ddpm.py:174-205)."""
+    from audiopure_amd import _native as N
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg, net, _ = mini
+    B, L, n = 2, 16000, 3
+    eng = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=n)._tables()      # installs the schedule tables
+    ws = eng.workspace(B, L, dev)
+    x0 = torch.from_numpy(synth.waveforms(B, L, seed=7)).to(dev)
+    z = torch.stack([torch.from_numpy(synth.noise(d, B, L, seed=7)) for d in range(n)]).to(dev).contiguous()
+    out = torch.empty_like(x0)
+    N.check(eng.lib.ap_purify_ddpm(eng.ctx, N.ptr(x0), n, 1, N.ptr(z), 0, 0, N.ptr(out), B, L, ws.data_ptr(), ws.numel(),
+                                   N.stream()), "ap_purify_ddpm")
+    assert rel_err(out.cpu().numpy(), golden["mini/ddpm_n3"]) < TOL_CHAIN
+
+    fnet, _ = _net(dict(synth.FULL_WAVENET_CONFIG), dev)
+    feng = DiffWave(model=fnet, diffusion_hyperparams=dh, reverse_timestep=25)._tables()
+    fws = feng.workspace(B, L, dev)
+    xf = torch.from_numpy(synth.waveforms(B, L, seed=1234)).to(dev)
+    N.check(feng.lib.ap_one_shot_denoise(feng.ctx, N.ptr(xf), 25, N.ptr(out), B, L, fws.data_ptr(), fws.numel(), N.stream()),
+            "ap_one_shot_denoise")
+    assert rel_err(out.cpu().numpy(), golden["full/one_shot_t25"]) < TOL_EVAL
 
 
 def test_chunked_batches_equal_one_call(mini, dh, dev):

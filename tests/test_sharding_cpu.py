@@ -52,6 +52,17 @@ def test_world2_gather_equals_single_process(tmp_path, n_total):
     assert np.array_equal(np.load(out), _scores(0, n_total).numpy())
 
 
+def test_world8_uneven_gather_equals_single_process(tmp_path):
+    """BASELINE configs[2]'s rank count with a batch that does not divide: 4099 clips over 8 ranks (shards of 513 / 512),
+    the padded all_gather trimmed back to the global order."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "g8.npy")
+    mp.spawn(_worker, args=(8, port, 4099, out), nprocs=8, join=True)
+    assert np.array_equal(np.load(out), _scores(0, 4099).numpy())
+
+
 def test_single_process_passthrough():
     x = torch.arange(12.0).view(4, 3)
     assert all_gather_scores(x, 4) is x
@@ -79,6 +90,28 @@ def test_bench_self_launches_its_ranks_as_children_and_prints_one_line():
     assert len(rk["rank_elapsed_s"]) == 2 and rk["rank_elapsed_min_s"] <= rk["rank_elapsed_max_s"]
     assert [d["index"] for d in rk["devices"]] == [0, 1]
     assert out["ms_per_step"] * out["steps"] >= rk["rank_elapsed_min_s"] * 1e3 * 0.5
+
+
+def test_bench_eight_rank_rehearsal():
+    """The driver's SCALE command form at N = 8 (`python bench.py --gpus 8 ...`), rehearsed on CPU / gloo: eight child ranks,
+    eight device descriptors, one line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1",
+                        "--batch", "4"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    rk = out["ranks"]
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 32 and out["scaling"] == "weak"
+    assert rk["backend"] == "gloo" and rk["ranks"] == 8 and rk["distinct_devices"] == 8 and len(rk["rank_elapsed_s"]) == 8
+    assert [d["index"] for d in rk["devices"]] == list(range(8))
+    assert len({d["pci_bus_id"] for d in rk["devices"]}) == 8
 
 
 def test_bench_power_sampler_is_optional_evidence():
