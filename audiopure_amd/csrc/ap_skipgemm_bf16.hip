@@ -10,7 +10,7 @@
 //
 // One persistent workgroup per CU (8 waves; wave w owns skip rows [32w, 32w + 32) x 128 columns = 64 accumulator registers),
 // a chunk = one layer's 256 k:
-//   * g tile: global -> registers (8 x 16 B per thread, requested one chunk ahead) -> ds_write_b128 into the other of two
+//   * g tile: global -> registers (8 x 16 B per thread, requested two chunks ahead) -> ds_write_b128 into the other of two
 //     [column][channel] images with 528-byte rows (the block kernel's g image: conflict-free ds_read_b128 B fragments);
 //   * weights: the skip rows of the block's packed W2 image ([wave][row tile 1][k-step][lane][8 bf16]), L2 -> registers through a
 //     ring of one chunk (16 fragments): a fragment is replaced right behind its last MFMA by the same k-step's of the next chunk,
@@ -86,27 +86,38 @@ __global__ __launch_bounds__(512, 2) void skipgemm_bf16_kernel(
     t0 = __builtin_amdgcn_readfirstlane((tl % ntiles) * SPT);
   };
 
-  // staging unit: piece p = tid + 512 i -> column 2 wave + (lane >> 5) + 16 i, 16-byte piece q = lane & 31 of its 512-byte row
-  const int colw = 2 * wave + (lane >> 5), q = lane & 31;
-  u32x4 st[8];
-  auto issue_g = [&](int slot, int b, int t0) {
+  // staging unit: piece p = tid + 512 i -> column 2 wave + (lane >> 5) + 16 i, 16-byte piece q = lane & 31 of its 512-byte row.
+  // Two register sets: inside a tile the image of chunk k + 2 is requested at the top of chunk k (two chunks = 128 KB per CU in
+  // flight; one chunk in flight left the HBM pipe empty between a chunk's wait and the next request: 3.7 TB/s), across a tile
+  // boundary one chunk ahead (the epilogue's skip rows need the registers).
+  // (the lane's geometry is re-derived from a lane id read on the spot -- volatile asm, not hoisted out of the tile loop: kept
+  //  across the loop the eight offsets of each side are spilled, and a scratch reload is a vector-memory load whose wait drains
+  //  every request in flight)
+  u32x4 st[2][8];
+  auto issue_g = [&](u32x4(&dst)[8], int slot, int b, int t0) {
     const __amdgpu_buffer_rsrc_t rs = g_rsrc(slot, b);
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const unsigned v0 = (unsigned)(t0 + 2 * wave + (ln >> 5)) * 512u + (unsigned)(ln & 31) * 16u;
 #pragma unroll
     for (int i = 0; i < 8; i++)                                  // (a column at or past L lies past the image: the range check returns zeros)
-      st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(t0 + colw + 16 * i) * 512u + (unsigned)q * 16u, 0, 2));
+      dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, v0 + (unsigned)(16 * i) * 512u, 0, 2));
   };
-  auto write_g = [&](unsigned char *buf) {
+  auto write_g = [&](const u32x4(&src)[8], unsigned char *buf) {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    unsigned char *d0 = buf + (2 * wave + (ln >> 5)) * (SGS * 2) + (ln & 31) * 16;
 #pragma unroll
-    for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4 *>(buf + (colw + 16 * i) * (SGS * 2) + q * 16) = st[i];
+    for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4 *>(d0 + 16 * i * (SGS * 2)) = src[i];
   };
 
   int b_cur, t0_cur;
   tile_bt(tile, b_cur, t0_cur);
-  issue_g(0, b_cur, t0_cur);
+  issue_g(st[0], 0, b_cur, t0_cur);
   bf16x8 a[NKS];                                                 // weight fragments of the chunk in flight / next chunk (ring of one chunk)
 #pragma unroll
   for (int ks = 0; ks < NKS; ks++) a[ks] = ld_a(0, ks);
-  write_g(lds);
+  write_g(st[0], lds);
   __syncthreads();                                               // first image and the bias sums visible
   int par = 0;                                                   // image the next chunk computes from
 
@@ -135,24 +146,36 @@ __global__ __launch_bounds__(512, 2) void skipgemm_bf16_kernel(
     float pre[4][16];
     const __amdgpu_buffer_rsrc_t srs = uni_rsrc((uint64_t)(skip + (size_t)b * C * L), clip_bytes);
 
-    // one chunk: 16 k-steps x 4 column tiles from image `par`; the next chunk's image is requested first and written last
-    auto chunk = [&](int nslot, int nb, int nt0, auto last_tag) {
-      constexpr bool LAST = decltype(last_tag)::value;
+    // one chunk k: 16 k-steps x 4 column tiles from image `par`.  Image requests at its top, by kind: first chunk of a tile (0):
+    // chunks 1 and 2 -> sets 1 and 0; a middle chunk (1; P = k & 1): chunk k + 2 -> set P; the last chunk (2): the NEXT tile's
+    // chunk 0 -> set 0.  At its end the next chunk's image (set 1 / P ^ 1 / 0) goes to the other LDS image, then the barrier.
+    auto chunk = [&](int k, auto kind_tag, auto p_tag) {
+      constexpr int KIND = decltype(kind_tag)::value, P = decltype(p_tag)::value;
+      constexpr bool LAST = KIND == 2;
+      constexpr int WSET = KIND == 0 ? 1 : KIND == 1 ? (P ^ 1) : 0;
       const unsigned char *gb = lds + par * GB + rdoff;
-      issue_g(nslot, nb, nt0);
+      if constexpr (KIND == 0) {
+        issue_g(st[1], 1, b, t0);
+        if (nl >= 3) issue_g(st[0], 2, b, t0);
+      } else if constexpr (KIND == 1) {
+        if (k + 2 <= nl - 1) issue_g(st[P], k + 2, b, t0);
+      } else {
+        issue_g(st[0], 0, b_nxt, t0_nxt);
+      }
+      const int nslot = LAST ? 0 : k + 1;
       __builtin_amdgcn_sched_barrier(0);
-      bf16x8 ba[4], bb[4];
-      auto rdg = [&](bf16x8(&bq)[4], int ks) {
+      bf16x8 bv[4];                                              // a column tile's B fragment is re-read for the next k-step right behind its MFMA
+      auto rdb = [&](int ct, int ks) { return *reinterpret_cast<const bf16x8 *>(gb + (32 * ct) * (SGS * 2) + ks * 32); };
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(gb + (32 * ct) * (SGS * 2) + ks * 32);
-      };
-      rdg(ba, 0);
+      for (int ct = 0; ct < 4; ct++) bv[ct] = rdb(ct, 0);
 #pragma unroll
       for (int ks = 0; ks < NKS; ks++) {
-        if (ks + 1 < NKS) { if (ks & 1) rdg(ba, ks + 1); else rdg(bb, ks + 1); }
 #pragma unroll
-        for (int ct = 0; ct < 4; ct++)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], (ks & 1) ? bb[ct] : ba[ct], acc[ct], 0, 0, 0);
+        for (int ct = 0; ct < 4; ct++) {
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bv[ct], acc[ct], 0, 0, 0);
+          if (ks + 1 < NKS) bv[ct] = rdb(ct, ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         a[ks] = ld_a(nslot, ks);                                 // the same k-step of the next chunk
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -179,14 +202,25 @@ __global__ __launch_bounds__(512, 2) void skipgemm_bf16_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      write_g(lds + (par ^ 1) * GB);
+      write_g(st[WSET], lds + (par ^ 1) * GB);
       __syncthreads();
       par ^= 1;
     };
 
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    if (nl >= 2) {
+      chunk(0, K0{}, K0{});
+      int k = 1;
 #pragma unroll 1
-    for (int slot = 0; slot + 1 < nl; slot++) chunk(slot + 1, b, t0, std::false_type{});
-    chunk(0, b_nxt, t0_nxt, std::true_type{});
+      for (; k + 1 <= nl - 2; k += 2) {
+        chunk(k, K1{}, K1{});
+        chunk(k + 1, K1{}, K0{});
+      }
+      if (k <= nl - 2) chunk(k, K1{}, K1{});
+    }
+    chunk(nl - 1, K2{}, K0{});
 
     // epilogue: MFMA layout (4 rows x 1 column per lane) -> wave-private patch (in the image just consumed: every wave is past the
     // chunk's barrier) -> 1 row x 4 columns per lane -> 16-byte read-modify-write

@@ -85,11 +85,12 @@ class NativeEngine:
         self.ws = None
         self.max_chunk = 512
         self.loaded_key = None
-        # AP_PREC_BF16, deferred-skip form (include/audiopure.h, ap_ctx_set_skip_group): layers per skip GEMM.  None = chosen per
-        # (B, L) from the memory that is free (each layer of a group keeps a [B][L][C] bf16 image: 8.2 MB per clip-second);
-        # 0 = the fused block with one read-modify-write of skip per layer.
-        self.skip_group = None
-        self._group_of = {}
+        # AP_PREC_BF16, deferred-skip form (include/audiopure.h, ap_ctx_set_skip_group): layers per skip GEMM.  A FIXED number
+        # (never derived from the batch or from free memory): the grouping sets the fp32 summation order of skip, and a clip's
+        # result must not depend on the batch it travels in (tests: a 512-clip run equals the 2-clip runs bit for bit).  Each
+        # layer of a group keeps a [B][L][C] bf16 image (8.2 MB per clip-second): 18 layers = 147 MB per clip on top of the
+        # 49 MB of activations -- where that does not fit, `chunks` walks the batch in smaller calls.  0 = the fused block.
+        self.skip_group = min(self.SKIP_GROUP, cfg["num_res_layers"])
         self._ds_ok = (precision == N.AP_PREC_BF16 and cfg["res_channels"] == 256 and cfg["skip_channels"] == 256)
 
     def __del__(self):
@@ -116,46 +117,43 @@ class NativeEngine:
         a, b = N.farr(betas.detach().cpu().float().tolist()), N.farr(ac.detach().cpu().float().tolist())
         N.check(self.lib.ap_ctx_set_sde_schedule(self.ctx, a, b, len(a)), "ap_ctx_set_sde_schedule")
 
-    SKIP_GROUPS = (36, 18, 12, 9, 6, 4, 3, 2)      # candidates, largest first
-    SKIP_WS_FRACTION = 0.55                          # of the device memory that is free (the current workspace counted as free)
+    SKIP_GROUP = 18                                  # two skip GEMMs per 36-layer evaluation (timing: tools/ab_bf16_ds.py)
+    WS_FRACTION = 0.7                                # of the device memory that is free (the current workspace counted as free)
 
-    def _pick_skip_group(self, B: int, L: int, device) -> int:
-        if not self._ds_ok:
-            return 0
-        if self.skip_group is not None:
-            return int(self.skip_group)
-        key = (B, L, device)
-        if key not in self._group_of:
-            NL = self.cfg.num_res_layers
-            try:
-                free, _ = torch.cuda.mem_get_info(device)
-                free += max(torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device), 0)
-            except (RuntimeError, AssertionError):
-                free = 0
-            free += self.ws.numel() if self.ws is not None and self.ws.device == device else 0
-            N.check(self.lib.ap_ctx_set_skip_group(self.ctx, 0), "ap_ctx_set_skip_group")
-            base = self.lib.ap_workspace_bytes(self.ctx, B, L)
-            slot = B * L * self.cfg.res_channels * 2
-            pick = 0
-            for g in self.SKIP_GROUPS:
-                if g <= NL and base + g * slot <= self.SKIP_WS_FRACTION * free:
-                    pick = g
-                    break
-            self._group_of[key] = pick
-        return self._group_of[key]
+    def _sync_group(self):
+        if self._ds_ok:                              # the context's group size and the workspace handed over go together
+            N.check(self.lib.ap_ctx_set_skip_group(self.ctx, int(self.skip_group or 0)), "ap_ctx_set_skip_group")
 
     def workspace(self, B: int, L: int, device) -> torch.Tensor:
-        if self._ds_ok:                              # the context's group size and the workspace handed over go together
-            N.check(self.lib.ap_ctx_set_skip_group(self.ctx, self._pick_skip_group(B, L, device)), "ap_ctx_set_skip_group")
+        self._sync_group()
         need = self.lib.ap_workspace_bytes(self.ctx, B, L)
         if self.ws is None or self.ws.numel() < need or self.ws.device != device:
             self.ws = None
             self.ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self.ws
 
-    def chunks(self, B: int):
-        for s in range(0, B, self.max_chunk):
-            yield s, min(B, s + self.max_chunk)
+    def clips_that_fit(self, L: int, device) -> int:
+        """How many clips of length L one call can take with the memory that is free now (>= 1)."""
+        self._sync_group()
+        per_clip = max(self.lib.ap_workspace_bytes(self.ctx, 2, L) - self.lib.ap_workspace_bytes(self.ctx, 1, L), 1)
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+            free += max(torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device), 0)
+        except (RuntimeError, AssertionError):
+            return self.max_chunk
+        free += self.ws.numel() if self.ws is not None and self.ws.device == device else 0
+        return max(1, int(self.WS_FRACTION * free) // per_clip)
+
+    def chunks(self, B: int, L: int = 0, device=None):
+        """Clip ranges of one native call each: at most ``max_chunk`` clips and -- when the clip length is given -- no more than
+        the workspace of which fits the free memory.  Results do not depend on the split (noise is keyed on the global index)."""
+        step = self.max_chunk
+        if L and device is not None:
+            self._sync_group()
+            if self.ws is None or self.ws.device != device or self.ws.numel() < self.lib.ap_workspace_bytes(self.ctx, min(B, step), L):
+                step = min(step, self.clips_that_fit(L, device))
+        for s in range(0, B, step):
+            yield s, min(B, s + step)
 
 
 class WaveNet_Speech_Commands(nn.Module):
@@ -250,7 +248,7 @@ class WaveNet_Speech_Commands(nn.Module):
         x = x.detach().float().contiguous()
         B, _, L = x.shape
         out = torch.empty_like(x)
-        for s, e in eng.chunks(B):
+        for s, e in eng.chunks(B, L, x.device):
             ws = eng.workspace(e - s, L, x.device)
             N.check(eng.lib.ap_eps_fwd(eng.ctx, N.ptr(x[s:e]), float(step), N.ptr(out[s:e]), e - s, L, ws.data_ptr(),
                                        ws.numel(), N.stream()), "ap_eps_fwd")

@@ -93,7 +93,7 @@ class DiffWave(torch.nn.Module):
         z_all, seed, off = self._draws(n_draws, x)
         out = torch.empty_like(x)
         arr = (N.ApStep * len(steps))(*[N.ApStep(*s) for s in steps]) if steps else None
-        for s, e in eng.chunks(B):
+        for s, e in eng.chunks(B, L, x.device):
             ws = eng.workspace(e - s, L, x.device)
             zc = z_all[:, s:e].contiguous() if z_all is not None else None
             N.check(eng.lib.ap_purify_chain(eng.ctx, N.ptr(x[s:e]), float(qa), float(qs), arr, len(steps), N.ptr(zc),
@@ -165,7 +165,7 @@ class DiffWave(torch.nn.Module):
             return self.model.eps(x, float(t)), self._chain(x, [(float(t), ca, cb, 0.0, 0)]), dh["Sigma"][t]
         eps, mu = torch.empty_like(x), torch.empty_like(x)
         B, _, L = x.shape
-        for s, e in eng.chunks(B):
+        for s, e in eng.chunks(B, L, x.device):
             ws = eng.workspace(e - s, L, x.device)
             N.check(eng.lib.ap_eps_affine(eng.ctx, N.ptr(x[s:e]), float(t), ca, cb, N.ptr(eps[s:e]), N.ptr(mu[s:e]),
                                           e - s, L, ws.data_ptr(), ws.numel(), N.stream()), "ap_eps_affine")

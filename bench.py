@@ -76,7 +76,7 @@ PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32)", "bf16": "bf16",
 
 PMC_FILES = {"f32": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3_f32s_pmc_traffic.json", "r2_f32s_pmc_traffic.json"],
              "f32h": ["r3_f32h_pmc_traffic.json", "r2_f32h_pmc_traffic.json"],
-             "bf16": ["r3_bf16_pmc_traffic.json", "r2_bf16_pmc_traffic.json"]}
+             "bf16": ["r4_bf16_pmc_traffic.json"]}
 
 
 class PowerSampler:
@@ -356,6 +356,7 @@ def main():
                     help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
+    ap.add_argument("--no-caller-shapes", action="store_true", help="skip the callers' batch shapes leg (B = 1, 2, 10, 50, ...)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + gather protocol; no kernels")
     ap.add_argument("--chunk", type=int, default=0,
                     help="clips per chain call (0 = the engine's default for the mode): the batch of a step is walked in chunks "
@@ -407,16 +408,19 @@ def main():
     # synthetic 0.5*U(-1,1) clips, generated on device (resident in HBM before timing)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
-    x0 = (torch.rand((B, 1, L), device=dev, generator=g) - 0.5).contiguous()
+    x0_full = (torch.rand((B, 1, L), device=dev, generator=g) - 0.5).contiguous()
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_mode(precision, steps, warmup, sampler=None, n=n):
-        """W untimed + K timed passes of the hot path in one arithmetic mode -> (elapsed s, kernel ms, launches)."""
+    def run_mode(precision, steps, warmup, sampler=None, n=n, batch=None):
+        """W untimed + K timed passes of the hot path in one arithmetic mode -> (elapsed s, kernel ms, launches).
+        `batch`: the first `batch` clips of the step's batch (the callers' shapes leg); default the whole batch."""
         sampler = sampler or args.sampler
+        x0 = x0_full if batch is None else x0_full[:batch].contiguous()
+        B = x0.shape[0]
         net.set_precision(precision)
         dw = DiffWave(model=net, diffusion_hyperparams=calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG),
                       reverse_timestep=n)
@@ -449,16 +453,20 @@ def main():
                 fence()
                 elapsed = time.perf_counter() - t0
             run_mode.power = ps.result()
-        tot_ms, launches = C.c_double(), C.c_int64()
-        N.check(eng.lib.ap_profile_read(eng.ctx, C.byref(tot_ms), C.byref(launches)))
+        ms2, n2 = (C.c_double * 2)(), (C.c_int64 * 2)()            # [0] residual-block launches, [1] skip-GEMM launches (bf16 mode)
+        N.check(eng.lib.ap_profile_read_split(eng.ctx, ms2, n2))
         N.check(eng.lib.ap_profile_enable(eng.ctx, 0))
         assert torch.isfinite(lp).all()
         run_mode.local_elapsed = elapsed                          # this rank's own clock, before the max over ranks
+        run_mode.split = {"block_ms": ms2[0] / max(n2[0], 1), "block_launches": int(n2[0]),
+                          "skip_gemm_ms_per_block_launch": ms2[1] / max(n2[0], 1), "skip_gemm_launches": int(n2[1]),
+                          "skip_gemm_ms_per_launch": ms2[1] / max(n2[1], 1), "skip_group": int(getattr(eng, "skip_group", 0) or 0)}
         if use_dist:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, tot_ms.value / max(launches.value, 1), int(launches.value)
+        # per residual LAYER: the block launch plus its share of the group's skip GEMM (zero in the fp32-class modes)
+        return elapsed, (ms2[0] + ms2[1]) / max(n2[0], 1), int(n2[0])
 
     def roofline(precision, k_ms, launches):
         Bl = getattr(run_mode, "chunk", B)                       # clips per residual-block launch
@@ -493,9 +501,20 @@ def main():
                     "executed_f16_TFLOPs": round(3 * achieved, 1)}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "resblock_bf16p_kernel (persistent, every dilation)", "achieved": round(gbs, 1), "peak": 8000.0,
+            sp = getattr(run_mode, "split", {})
+            roof = {"bound": "hbm",
+                    "kernel": "resblock_bf16p_kernel<DS> (persistent; h' + bf16 gate image) + skipgemm_bf16_kernel (one K-concatenated "
+                              f"skip GEMM per {sp.get('skip_group', 0)} layers)" if sp.get("skip_group") else "resblock_bf16p_kernel (persistent, fused skip)",
+                    "achieved": round(gbs, 1), "peak": 8000.0,
                     "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": traffic,
                     "mfma_TFLOPs": round(achieved, 1), "mfma_frac_of_2500": round(achieved / 2500.0, 4),
+                    "per_layer_ms": {"block_launch": round(sp.get("block_ms", k_ms), 4),
+                                     "skip_gemm_share": round(sp.get("skip_gemm_ms_per_block_launch", 0.0), 4),
+                                     "skip_gemm_launches": sp.get("skip_gemm_launches", 0),
+                                     "skip_gemm_ms_per_launch": round(sp.get("skip_gemm_ms_per_launch", 0.0), 4)},
+                    "accounting": "achieved = the layer's ALGORITHMIC bytes (read h, write h', read + write fp32 skip: 65.5 MB per clip, "
+                                  "SURVEY 8d) / (block launch + its share of the group's skip GEMM); the deferred-skip form moves fewer "
+                                  "bytes than that (h in, h' + a bf16 gate image out, the image in once more, skip once per group)",
                     "note": "the kernel runs at the board's 1400 W power cap (see this leg's `power`); calibrated with bare MFMA and "
                             "HBM-copy kernels (profiles/r3_mfma_power_calibration.txt: ~0.63 pJ per bf16 flop on random operands, ~120 pJ "
                             "per HBM byte) the ceiling of this algorithm under the cap is 0.48-0.54 of the 8 TB/s roofline; a synthetic kernel with the same "
@@ -508,6 +527,7 @@ def main():
 
     elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
     head_power = run_mode.power
+    head_roof = roofline(args.precision, k_ms, launches)        # (now: run_mode.chunk / .split describe the run just made)
     ranks = rank_evidence(use_dist, run_mode.local_elapsed, device_descriptor(torch, local), "nccl")
     # the other arithmetic modes of the same path, measured in the same run (N = 1 only: they are extra evidence,
     # not the headline): same inputs, same chain, same timing brackets
@@ -539,10 +559,77 @@ def main():
         net.set_precision(args.precision)
         other_configs["configs[4]"] = bench_config4(dev, max(1, min(args.steps, 5)))
 
+    # the batch shapes the reference's callers use (adaptive_attack_eval.py:47,156-160: --batch_size 10, FAKEBOB's 10 x 50 copies;
+    # certified_robust.py:46-57: one-shot denoise of a batch of copies; white_box_attack.py:392,437-439: PGD through the purifier
+    # at B = 10; BASELINE configs[0]: B = 2, n = 1): per-clip rate of the same path relative to the 512-clip batch
+    caller_shapes = None
+    if world == 1 and not args.no_other_configs and not args.no_caller_shapes:
+        from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+        dh_ = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+        ref_rate = {"f32": (world * B * args.steps / elapsed) if args.precision == "f32" else others.get("f32", {}).get("value"),
+                    "bf16": (world * B * args.steps / elapsed) if args.precision == "bf16" else others.get("bf16", {}).get("value")}
+
+        def timed(fn, reps=2):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps
+
+        caller_shapes = {"note": "DDPM n=5 + M5 at the callers' batch sizes: utterances/s and the per-clip rate relative to this run's "
+                                 f"{B}-clip batch in the same arithmetic mode; then one_shot_denoise + M5 at B=10 (certification), one "
+                                 "white-box gradient step (RevDiffWave t=5 + M5 + nll_loss, forward + backward w.r.t. the audio) at B=10, and "
+                                 "BASELINE configs[0]'s B=2, n=1 on the GPU", "ddpm_n5": {}}
+        for prec in ("f32", "bf16"):
+            rows = {}
+            for b in (1, 2, 10, 50) + ((500,) if prec == "bf16" else ()):
+                if b > B:
+                    continue
+                st = 2
+                e_, k_, _ = run_mode(prec, st, 1, batch=b)
+                v = b * st / e_
+                rows[f"B={b}"] = {"value": round(v, 3), "unit": "utterances/s", "ms_per_step": round(e_ * 1e3 / st, 3),
+                                  "layer_ms": round(k_, 4),
+                                  "per_clip_rate_vs_full_batch": round(v / ref_rate[prec], 4) if ref_rate.get(prec) else None}
+            caller_shapes["ddpm_n5"][prec] = rows
+        x10 = x0_full[:min(10, B)].contiguous()
+        y10 = torch.zeros(x10.shape[0], dtype=torch.long, device=dev)
+        one_shot, grad_step = {}, {}
+        for prec in ("f32", "bf16"):
+            net.set_precision(prec)
+            dwc = DiffWave(model=net, diffusion_hyperparams=dh_, reverse_timestep=n)
+            dwc.set_noise_source(("philox", 1234, 0))
+            with torch.no_grad():
+                t_os = timed(lambda: m5(dwc.one_shot_denoise(x10)))
+            one_shot[prec] = {"B": x10.shape[0], "ms": round(t_os * 1e3, 3), "clips_per_s": round(x10.shape[0] / t_os, 2)}
+            if prec == "f32":
+                runner = RevDiffWave.from_model(dwc, types.SimpleNamespace(t=n, score_type="guided_diffusion", rand_t=False, t_delta=0,
+                                                                             use_bm=False, sample_step=1))
+                sysg = AcousticSystem(classifier=m5, transform=None, defender=runner, defense_type="wave")
+
+                def gstep():
+                    xg = x10.clone().requires_grad_(True)
+                    torch.nn.functional.nll_loss(sysg(xg, True), y10).backward()
+                    return xg.grad
+
+                t_g = timed(gstep)
+                with torch.no_grad():
+                    t_f = timed(lambda: sysg(x10, True), reps=1)
+                grad_step[prec] = {"B": x10.shape[0], "ms": round(t_g * 1e3, 2), "clips_per_s": round(x10.shape[0] / t_g, 2),
+                                   "forward_only_ms": round(t_f * 1e3, 2), "backward_over_forward": round(t_g / t_f, 2)}
+        caller_shapes["one_shot_denoise_B10"] = one_shot
+        caller_shapes["white_box_gradient_step_B10"] = grad_step
+        e0_, k0_, _ = run_mode("f32", 3, 1, n=1, batch=min(2, B))
+        caller_shapes["configs[0]_on_gpu"] = {"workload": "DiffWave DDPM n=1 + M5, batch=2, fp32 (BASELINE configs[0], the CPU reference's case)",
+                                              "value": round(min(2, B) * 3 / e0_, 3), "unit": "utterances/s", "ms_per_step": round(e0_ * 1e3 / 3, 3)}
+        net.set_precision(args.precision)
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * B * args.steps / elapsed
-        roof = roofline(args.precision, k_ms, launches)
+        roof = head_roof
         out = {
             "metric": f"purified 1s@16kHz utterances/sec at {n} reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
@@ -561,6 +648,8 @@ def main():
             out["other_modes"] = others
         if other_configs:
             out["other_configs"] = other_configs
+        if caller_shapes:
+            out.setdefault("other_configs", {})["caller_shapes"] = caller_shapes
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

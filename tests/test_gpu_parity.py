@@ -528,12 +528,8 @@ def test_bf16_eps_is_the_same_for_every_skip_group_size(dev, L):
             eng.skip_group = G
             got = net.eps(x, 7.0)
             assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 3e-3, G
-        eng.skip_group = None                                    # the engine's own choice (memory permitting: the largest group)
-        got = net.eps(x, 7.0)
-        assert eng._pick_skip_group(3, L, x.device) > 0
-        assert rel_err(got.cpu().numpy(), ref.cpu().numpy()) < 3e-3
     finally:
-        eng.skip_group = None
+        eng.skip_group = min(eng.SKIP_GROUP, 14)                 # the engine's fixed default (never a function of batch or memory)
 
 
 TOL_BF16_CHAIN = 5e-3          # bf16-mode chain vs the bf16-emulating chain oracle (same operand roundings, fp32 elsewhere)
