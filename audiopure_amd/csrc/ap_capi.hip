@@ -410,7 +410,8 @@ int run_net(ap_ctx *ctx, const float *x, float step, const Ws &w, int B, int L, 
     for (int n0 = 0; n0 < ctx->NL; n0 += G) {
       const int nl = ctx->NL - n0 < G ? ctx->NL - n0 : G;
       for (int n = n0; n < n0 + nl; n++) {
-        rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, hout, nullptr, 0, B, L, st, nullptr, nullptr,
+        // (the last layer's h' is never read -- WaveNet.py:131-135 returns the skip sum only: null = leave res_conv and its store out)
+        rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, n + 1 == ctx->NL ? nullptr : hout, nullptr, 0, B, L, st, nullptr, nullptr,
                              w.gimg + (size_t)(n - n0) * w.gslot);
         if (rc) return rc;
         float *t = hin; hin = hout; hout = t;
@@ -470,7 +471,7 @@ extern "C" int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const 
 
 extern "C" int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
                                     void *g_image, int B, int L, void *stream) {
-  if (!ctx || !ctx->loaded || !h_in || !part_t_layer || !h_out || !g_image) { set_error("ap_resblock_fwd_gate: not loaded / null"); return -22; }
+  if (!ctx || !ctx->loaded || !h_in || !part_t_layer || !g_image) { set_error("ap_resblock_fwd_gate: not loaded / null"); return -22; }
   if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd_gate: layer=%d B=%d L=%d", layer, B, L); return -22; }
   if (h_in == h_out) { set_error("ap_resblock_fwd_gate: h_out must not alias h_in"); return -22; }
   if (ctx->cfg.precision != AP_PREC_BF16) { set_error("ap_resblock_fwd_gate: AP_PREC_BF16 only"); return -22; }

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void conv2d_few_kernel(ConvArgs a) {
   float acc[MO];
 #pragma unroll
   for (int m = 0; m < MO; m++) acc[m] = 0.f;
+#pragma unroll 4                                                // (four channels' taps in flight: the loop is load-latency bound)
   for (int ci = 0; ci < a.Cin; ci++) {
     const float *xc = xb + (size_t)ci * HW;
     const float *wk = wsm + (size_t)ci * KK * MO;
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(256, 5) void conv2d_f32_big2_kernel(ConvArgs a, con
   // im2col tile: P1 keeps [k'][column] (its staging writes four pixels of one k' at once, 4-byte fragment reads); the gather form
   // keeps [column][k'] with 80-byte rows (conflict-free 16-byte writes of a thread's EPT consecutive k' and 16-byte fragment reads)
   constexpr int RS = BK + 4;
-  __shared__ __attribute__((aligned(16))) float Bs_[P1 ? 2 * BK * BN : 2 * BN * RS];
+  // (at least 4 x 32 x 32 floats: the epilogue's four wave-private output patches alias it)
+  constexpr int BS_FLOATS = (P1 ? 2 * BK * BN : 2 * BN * RS) > 4096 ? (P1 ? 2 * BK * BN : 2 * BN * RS) : 4096;
+  __shared__ __attribute__((aligned(16))) float Bs_[BS_FLOATS];
   auto Bs = [&](int buf, int k, int col) -> float & { return Bs_[P1 ? (buf * BK + k) * BN + col : (buf * BN + col) * RS + k]; };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -447,6 +450,49 @@ __global__ __launch_bounds__(256, 5) void conv2d_f32_big2_kernel(ConvArgs a, con
 #pragma unroll
       for (int q = 0; q < 2; q++) a0[x_][q] = a1[x_][q];
     __syncthreads();
+  }
+  // Epilogue.  The accumulator layout is 4 rows x 1 column per lane: stored as it is, a tile costs every thread 64 four-byte stores
+  // (+ 64 residual loads), as many memory instructions as ~16 chunks of the main loop -- the fixed cost that held the short-K
+  // layers (128 -> 128 3x3: 72 chunks) at 0.74 of the peak while K = 2 304 reached 0.85.  Where an image's pixel count is a
+  // multiple of four (every layer but the 1 x 1 maps) each 32 x 32 tile goes through a wave-private LDS patch (aliasing the
+  // im2col tile, free behind the loop's last barrier) and leaves as 1 row x 4 pixels per lane: 16-byte stores and residual loads.
+  if ((HoWo & 3) == 0) {
+    int ln;                                                     // (lane id read here: lane-derived values kept across the chunk loop for
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));   //  the epilogue's sake were spilled)
+    const int ej = ln & 31, ehh = ln >> 5, erow = ln >> 3, eq = ln & 7;
+    float *patch = Bs_ + wave * 1024;                           // [32 rows][32 columns], 128-byte rows (conflict-free both ways)
+    const size_t part_base = (size_t)zs * ((size_t)a.B * a.Cout * HoWo);
+#pragma unroll
+    for (int y_ = 0; y_ < NY; y_++) {
+      const int nn = n0 + 32 * NY * wn + 32 * y_ + 4 * eq;      // this lane's pixel quad (inside N or outside it as a whole)
+      const int ob = nn < N ? nn / HoWo : 0, op = nn < N ? nn - ob * HoWo : 0;
+#pragma unroll
+      for (int x_ = 0; x_ < NX; x_++) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; r++) patch[crowoff(r, ehh) * 32 + ej] = acc[x_][y_][r];
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const int row = erow + 8 * p;
+          const int m = m0 + 32 * NX * wm + 32 * x_ + row;
+          f32x4 v = *reinterpret_cast<const f32x4 *>(patch + row * 32 + 4 * eq);
+          if (nn < N && m < Mg) {
+            const int co = g * Mg + m;
+            const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
+            if (a.splits > 1) {                                 // raw partial sum; conv_splitk_reduce_kernel adds bias / residual / ReLU
+              *reinterpret_cast<f32x4 *>(a.part + part_base + off) = v;
+            } else {
+              if (a.bias) { const float bv = a.bias[co]; v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv; }
+              if (a.res) { const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.res + off); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+              if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+              *reinterpret_cast<f32x4 *>(a.out + ((size_t)ob * a.o_cstride + a.o_coff + co) * HoWo + op) = v;
+            }
+          }
+        }
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int y_ = 0; y_ < NY; y_++) {

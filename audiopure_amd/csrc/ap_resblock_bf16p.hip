@@ -228,7 +228,9 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // NOT run the skip half of GEMM2 or its read-modify-write of `skip`.  skipgemm_bf16_kernel (ap_skipgemm_bf16.hip) adds
 // sum_n W_skip,n g_n for a group of layers into `skip` in one K-concatenated GEMM.  h' is bit-identical to the fused form
 // (same pass-0 code); per tile and layer the block moves 131 KB in + 131 KB + 64 KB out instead of 262 + 262 KB.
-template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false, bool DS = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
+// NOH (with DS): the net's LAST layer -- its h' is never read (WaveNet.py:131-135 returns only the skip sum), so res_conv, the
+// residual's re-read of h and the h' store are left out: GEMM1, the gate and the g image only.
+template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false, bool DS = false, bool NOH = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
   constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
   static_assert(!UB || (WS < 0 && !M16), "UB: one staging form");
   static_assert(!DS || (!UB && !M16), "DS: the product staging forms only");
+  static_assert(!NOH || DS, "NOH: a form of the deferred-skip block");
   // cache policy: nt (aux bit 1) on the once-touched streams (the running skip rows in, both outputs out) and on the residual's
   // re-read of h (it hits what is still there and allocates nothing on a miss).  Only the tap loads and the weights allocate in
   // the XCD's L2, so h rows stay until the neighbouring tiles' taps and the residual have read them again: L2-miss reads 27.2 ->
@@ -869,10 +872,12 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
         bias[q] = v;
       }
     };
-    calc_evoff();
-    load_a4(p0, 0);
-    load_pre(hrs, I0{});                                         // the residual's h patch, first half (what fits beside the accumulators)
-    load_pre(hrs, I1{});
+    if constexpr (!NOH) {
+      calc_evoff();
+      load_a4(p0, 0);
+      load_pre(hrs, I0{});                                       // the residual's h patch, first half (what fits beside the accumulators)
+      load_pre(hrs, I1{});
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     const __amdgpu_buffer_rsrc_t srs = clip_rsrc(skip, b_cur);
@@ -932,18 +937,20 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     };
     // every gated column tile frees 32 accumulator registers: the rest of the h patch, then the first half of the skip rows
     gate_ct(I0{});
-    load_pre(hrs, I2{});
+    if constexpr (!NOH) load_pre(hrs, I2{});
     __builtin_amdgcn_sched_barrier(0);
     gate_ct(I1{});
-    load_pre(hrs, I3{});
+    if constexpr (!NOH) load_pre(hrs, I3{});
     __builtin_amdgcn_sched_barrier(0);
     gate_ct(I2{});
     if constexpr (!DS) load_pre1(I0{});
     __builtin_amdgcn_sched_barrier(0);
     gate_ct(I3{});
     if constexpr (!DS) load_pre1(I1{});
-    fetch_bias(I0{});
-    load_a4(p1, 4);
+    if constexpr (!NOH) {
+      fetch_bias(I0{});
+      load_a4(p1, 4);
+    }
     __builtin_amdgcn_sched_barrier(0);
     mark(26);
     __syncthreads();
@@ -1088,13 +1095,18 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
       // the ONE pass of this form (res_conv rows -> h'), in the place and with the request order the fused form gives its
       // last pass: the next tile's first chunk is in flight under the MFMAs, its pack and first fragments go out before the
       // stores, the stores drain behind the next tile's GEMM1
-      f32x16 ac[4];
-      gemm2_loop(ac, 0);
-      mark(30);
-      tile_head();
-      mark(31);
-      __builtin_amdgcn_sched_barrier(0);
-      epilogue(ac, pre, ors, RS, std::false_type{});
+      if constexpr (NOH) {
+        tile_head();
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        f32x16 ac[4];
+        gemm2_loop(ac, 0);
+        mark(30);
+        tile_head();
+        mark(31);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(ac, pre, ors, RS, std::false_type{});
+      }
       // g image -> HBM: 128 columns x 512 B, one 16-byte piece per lane and step (a wave moves two whole columns per step:
       // 1 KB contiguous on both sides; the padded 528-B LDS rows keep the 16-lane groups of ds_read_b128 on distinct banks)
       {
@@ -1190,9 +1202,14 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   if (gout) {                                                    // deferred-skip form: h' + the bf16 g image, no skip GEMM in the block
     if ((size_t)L * 512 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16: clip too long for the bf16 g image"); return -22; }
 #define AP_P_LAUNCH_DS(W, R)                                                                                                   \
-  resblock_bf16p_kernel<0, W, R, false, false, true><<<(unsigned)grid, 512, 0, st>>>(hin, pt, hout, nullptr, wlo, wbytes, w1_off, w2_off, blo, \
-                                                                                     bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr,   \
-                                                                                     nullptr, nullptr, gout)
+  do {                                                                                                                         \
+    if (hout)                                                                                                                  \
+      resblock_bf16p_kernel<0, W, R, false, false, true><<<(unsigned)grid, 512, 0, st>>>(                                      \
+          hin, pt, hout, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr, nullptr, nullptr, gout); \
+    else /* h' not wanted (the net's last layer) */                                                                            \
+      resblock_bf16p_kernel<0, W, R, false, false, true, true><<<(unsigned)grid, 512, 0, st>>>(                                \
+          hin, pt, nullptr, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr, nullptr, nullptr, gout); \
+  } while (0)
     if (rag) {
       if (ws == 1) AP_P_LAUNCH_DS(1, true);
       else if (ws == 2) AP_P_LAUNCH_DS(2, true);

@@ -88,8 +88,8 @@ class NativeEngine:
         # AP_PREC_BF16, deferred-skip form (include/audiopure.h, ap_ctx_set_skip_group): layers per skip GEMM.  A FIXED number
         # (never derived from the batch or from free memory): the grouping sets the fp32 summation order of skip, and a clip's
         # result must not depend on the batch it travels in (tests: a 512-clip run equals the 2-clip runs bit for bit).  Each
-        # layer of a group keeps a [B][L][C] bf16 image (8.2 MB per clip-second): 18 layers = 147 MB per clip on top of the
-        # 49 MB of activations -- where that does not fit, `chunks` walks the batch in smaller calls.  0 = the fused block.
+        # layer of a group keeps a [B][L][C] bf16 image (8.2 MB per clip-second): 36 layers = 295 MB per clip on top of the
+        # 49 MB of activations (B = 512: 176 GB of the 288) -- where that does not fit, `chunks` walks the batch in smaller calls.  0 = the fused block.
         self.skip_group = min(self.SKIP_GROUP, cfg["num_res_layers"])
         self._ds_ok = (precision == N.AP_PREC_BF16 and cfg["res_channels"] == 256 and cfg["skip_channels"] == 256)
 
@@ -117,7 +117,7 @@ class NativeEngine:
         a, b = N.farr(betas.detach().cpu().float().tolist()), N.farr(ac.detach().cpu().float().tolist())
         N.check(self.lib.ap_ctx_set_sde_schedule(self.ctx, a, b, len(a)), "ap_ctx_set_sde_schedule")
 
-    SKIP_GROUP = 18                                  # two skip GEMMs per 36-layer evaluation (timing: tools/ab_bf16_ds.py)
+    SKIP_GROUP = 36                                  # one skip GEMM per evaluation of the shipped net: skip is written once, never re-read
     WS_FRACTION = 0.7                                # of the device memory that is free (the current workspace counted as free)
 
     def _sync_group(self):

@@ -173,6 +173,7 @@ int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const float *part
  * skip tensor per layer.
  *   ap_resblock_fwd_gate: the block of ap_resblock_fwd without skip_conv: writes h_out (bit-identical to ap_resblock_fwd's) and
  *                         g_image [B][L][C] bf16 (512 bytes per sample, channels contiguous); `skip` is not touched.
+ *                         h_out may be NULL: res_conv and the h' store are left out (the net's last layer, whose h' nobody reads).
  *   ap_skip_gemm:         skip (+)= sum_{n = layer0 .. layer0 + n_layers - 1} (W_skip,n g_n + b_skip,n) with
  *                         g_images [n_layers][B][L][C] bf16 (slot n - layer0); accumulate_skip = 0 writes skip.
  *   ap_ctx_set_skip_group(G): G > 0 makes ap_eps_fwd / ap_purify_* run this form with groups of G layers (the workspace grows

@@ -464,6 +464,9 @@ def test_bf16_resblock_matches_bf16_emulating_oracle(dev, L, layer):
     N.check(eng.lib.ap_skip_gemm(eng.ctx, layer, 1, gimg.data_ptr(), N.ptr(sk2), 1, B, L, N.stream()))
     assert torch.equal(hout2, hout)
     assert torch.equal(sk2, sk)
+    gimg_noh = torch.zeros_like(gimg)                            # h_out = NULL (the net's last layer): the same g image, no h' written
+    N.check(eng.lib.ap_resblock_fwd_gate(eng.ctx, layer, N.ptr(hd), N.ptr(pt), None, gimg_noh.data_ptr(), B, L, N.stream()))
+    assert torch.equal(gimg_noh.view(torch.int16), gimg.view(torch.int16))
     sk3 = torch.full_like(sk2, 3.0)                              # accumulate_skip = 0 overwrites
     N.check(eng.lib.ap_skip_gemm(eng.ctx, layer, 1, gimg.data_ptr(), N.ptr(sk3), 0, B, L, N.stream()))
     assert rel_err(sk3.cpu().numpy(), s_q.numpy()) < 4e-3
