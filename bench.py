@@ -127,6 +127,7 @@ class PowerSampler:
             import threading
 
             def loop():
+                time.sleep(0.4)                                     # (the first poll would land before the leg's first kernel is running)
                 while not self.stop:
                     w, c, _ = self._read()
                     if w is not None and c is not None:
@@ -142,7 +143,7 @@ class PowerSampler:
             self.thread.join(timeout=15)
 
     def result(self):
-        if not self.samples:
+        if len(self.samples) < 2:                               # one poll says nothing about a leg of seconds
             return None
         ws, cs = [w for w, _ in self.samples], [c for _, c in self.samples]
         cap = self._read(("--showmaxpower",))[2]
