@@ -726,6 +726,33 @@ def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
             assert rel_err(outs["bf16"][k], outs["f32"][k]) < 3e-2, (B, L, layer, k)
 
 
+def test_bf16_deferred_skip_chain_is_hip_graph_capturable(dh, dev):
+    """The bf16 mode's two-kernel form (36 block launches + the skip GEMM per evaluation, ap_ctx_set_skip_group on the host side
+    only) captures into a HIP graph like the fp32 chain does, and a replay reproduces the eager result bit for bit."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, _ = _net(cfg, dev, seed=4)
+    net.set_precision("bf16")
+    x0 = torch.from_numpy(synth.waveforms(2, 2000, seed=4)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    dw.set_noise_source(("philox", 11, 0))
+    ref = dw(x0)                               # warm: engine, workspace and output allocations exist
+    assert net.engine().skip_group > 0
+    static_in = x0.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dw(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        out = dw(static_in)
+    static_in.copy_(x0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
 def test_c_entry_points_match_python_chains(mini, dh, dev):
     """ap_purify_ddpm / ap_purify_sde / ap_one_shot_denoise (coefficients computed inside the library from the installed
     tables) give the same result as the chains the Python classes build with ap_purify_chain."""
