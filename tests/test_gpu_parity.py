@@ -512,6 +512,35 @@ def test_bf16_skip_gemm_over_a_group_of_layers_matches_the_oracle_sum(dev, L, la
     assert rel_err(got, (sk_fused.cpu() - base).numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("B,L,layer0,nl,acc", [(1, 4, 0, 1, 0), (3, 130, 2, 2, 1), (2, 1001, 5, 5, 1), (7, 257, 0, 12, 0), (2, 4096, 0, 36, 1),
+                                               (5, 127, 30, 6, 0), (1, 16000, 35, 1, 1), (300, 128, 3, 3, 1)])
+def test_bf16_skip_gemm_alone_matches_a_plain_gemm(dev, B, L, layer0, nl, acc):
+    """ap_skip_gemm on RANDOM bf16 images (not produced by the block kernel), against the same sum written with torch matmuls on
+    the device's folded skip_conv weights rounded to bf16: isolates the kernel's tiling -- partial tiles, single-column-quad clips,
+    more tiles than CUs and fewer, groups of 1 .. 36 layers (odd and even chunk counts), write and accumulate -- from everything
+    around it.  Products of bf16 values are exact in fp32, so only the fp32 summation order differs: 2e-5 of max."""
+    from audiopure_amd import _native as N
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, _ = _net(cfg, dev)
+    net.set_precision("bf16")
+    eng = net.engine()
+    C_ = 256
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(B * 1000 + L + nl)
+    g = (torch.rand((nl, B, L, C_), device=dev, generator=gen) * 2 - 1).to(torch.bfloat16).contiguous()
+    base = torch.rand((B, C_, L), device=dev, generator=gen) - 0.5
+    ref = base.clone() if acc else torch.zeros_like(base)
+    for i in range(nl):
+        w = torch.empty((C_, C_), device=dev)
+        N.check(eng.lib.ap_ctx_get_folded(eng.ctx, 2, layer0 + i, N.ptr(w), w.numel(), N.stream()))
+        bias = net.residual_layer.residual_blocks[layer0 + i].skip_conv.bias.detach().float()
+        ref += torch.einsum("sc,blc->bsl", w.to(torch.bfloat16).float(), g[i].float()) + bias.view(1, C_, 1)
+    out = base.clone() if acc else torch.full_like(base, float("nan"))
+    N.check(eng.lib.ap_skip_gemm(eng.ctx, layer0, nl, g.data_ptr(), N.ptr(out), acc, B, L, N.stream()))
+    assert torch.isfinite(out).all()
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 2e-5
+
+
 @pytest.mark.parametrize("L", [16000, 1001])
 def test_bf16_eps_is_the_same_for_every_skip_group_size(dev, L):
     """ap_ctx_set_skip_group: groups of G layers per skip GEMM (G = 1 accumulates in the fused form's order: bit-identical eps;
