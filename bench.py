@@ -13,8 +13,8 @@ the global utterance index, one RCCL all_gather of the [B,10] log-probabilities 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself as CHILD processes
 (`python -m torch.distributed.run ... bench.py --gpus N ...`, before anything touches a GPU) and relays rank 0's line;
 `--dry-run` does the same on CPU with the gloo backend (launcher / sharding / gather plumbing only, no kernels).
-At N = 1 the same run then times the other arithmetic modes of the path (`other_modes`) and BASELINE configs[3] /
-configs[4] as their own workloads (`other_configs`), each with its own roofline object.
+At N = 1 the same run then times the bf16 mode of the path (`other_modes`; `--experimental-modes` adds the frozen f32s / f32h),
+BASELINE configs[3] / configs[4] as their own workloads and the callers' batch shapes (`other_configs`), each with its own roofline object.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused residual block, timed with HIP
 events on its launch stream inside the timed region) and `cpu_baseline` (the CPU oracle on BASELINE
@@ -357,6 +357,8 @@ def main():
                     help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
+    ap.add_argument("--experimental-modes", action="store_true",
+                    help="also time the frozen split-operand modes f32s / f32h under other_modes (about 50 s more)")
     ap.add_argument("--no-caller-shapes", action="store_true", help="skip the callers' batch shapes leg (B = 1, 2, 10, 50, ...)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + gather protocol; no kernels")
     ap.add_argument("--chunk", type=int, default=0,
@@ -534,7 +536,8 @@ def main():
     # not the headline): same inputs, same chain, same timing brackets
     others = {}
     if world == 1 and not args.no_other_modes:
-        for prec in ("f32s", "f32h", "bf16", "f32"):
+        # (f32s / f32h: experimental modes, frozen since round 3 -- timed only on request)
+        for prec in (("f32s", "f32h") if args.experimental_modes else ()) + ("bf16", "f32"):
             if prec == args.precision:
                 continue
             if prec == "f32" and args.precision != "f32":
