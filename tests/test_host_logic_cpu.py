@@ -133,3 +133,32 @@ def test_script_constructors_read_json_config_and_pkl_checkpoint(tmp_path):
         bad = tmp_path / "bad.pkl"
         torch.save({"state_dict": {}}, str(bad))
         create_diffwave_model(str(bad), str(conf), device=torch.device("cpu"))
+
+
+def test_engine_walks_a_batch_in_calls_that_fit_the_free_memory(monkeypatch):
+    """bf16 mode keeps one [B][L][C] bf16 gate image per layer of the skip group (ap_ctx_set_skip_group): 344 MB per clip-second
+    at the shipped config.  Where a batch's workspace exceeds the free device memory the engine splits the batch (results do
+    not depend on the split: noise is keyed on the global utterance index) -- it never changes the group size, which would
+    change the fp32 summation order of skip."""
+    import torch
+    from audiopure_amd import _native as N, synth
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import NativeEngine
+    eng = NativeEngine(dict(synth.FULL_WAVENET_CONFIG), N.AP_PREC_BF16)
+    assert eng.skip_group == 36
+    dev = torch.device("cpu")
+    eng._sync_group()                                            # (the context learns the group size with the first workspace request)
+    per_clip = eng.lib.ap_workspace_bytes(eng.ctx, 2, 16000) - eng.lib.ap_workspace_bytes(eng.ctx, 1, 16000)
+    assert 340e6 < per_clip < 350e6                              # 49 MB of activations + 36 x 8.2 MB of gate images
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(100e9), int(288e9)))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda d=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda d=None: 0)
+    fit = eng.clips_that_fit(16000, dev)
+    assert fit == int(0.7 * 100e9) // per_clip and 190 < fit < 210
+    spans = list(eng.chunks(512, 16000, dev))
+    assert spans[0] == (0, fit) and spans[-1][1] == 512 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert eng.skip_group == 36                                  # never traded for memory
+    eng.skip_group = 0                                           # the fused form needs 49 MB per clip: one call
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(280e9), int(288e9)))
+    assert list(eng.chunks(512, 16000, dev)) == [(0, 512)]
+    f32 = NativeEngine(dict(synth.FULL_WAVENET_CONFIG), N.AP_PREC_F32)
+    assert list(f32.chunks(700, 16000, dev)) == [(0, 512), (512, 700)]          # max_chunk still applies
