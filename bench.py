@@ -143,7 +143,7 @@ class PowerSampler:
             self.thread.join(timeout=15)
 
     def result(self):
-        if len(self.samples) < 2:                               # one poll says nothing about a leg of seconds
+        if not self.samples:
             return None
         ws, cs = [w for w, _ in self.samples], [c for _, c in self.samples]
         cap = self._read(("--showmaxpower",))[2]
