@@ -468,10 +468,29 @@ __global__ __launch_bounds__(256, 5) void conv2d_f32_big2_kernel(ConvArgs a, con
       const int ob = nn < N ? nn / HoWo : 0, op = nn < N ? nn - ob * HoWo : 0;
 #pragma unroll
       for (int x_ = 0; x_ < NX; x_++) {
+        // the tile's bias and residual operands are requested BEFORE its transposes: their latency runs under the LDS round trip
+        // instead of being exposed once per 32 x 32 tile
+        // (not for the first of four tiles: all 64 accumulator registers are still live there and the operands would be spilled)
+        const bool early = NX * NY < 4 || x_ + y_ > 0;
+        f32x4 rv[4];
+        float bv[4];
+        const bool fin = a.splits <= 1;
+        auto fetch_operands = [&]() {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            const int m = m0 + 32 * NX * wm + 32 * x_ + erow + 8 * p;
+            const bool ok = nn < N && m < Mg;
+            const int co = g * Mg + (ok ? m : 0);
+            bv[p] = (fin && a.bias && ok) ? a.bias[co] : 0.f;
+            rv[p] = (fin && a.res && ok) ? *reinterpret_cast<const f32x4 *>(a.res + ((size_t)ob * a.Cout + co) * HoWo + op) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        };
+        if (early) fetch_operands();
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < 16; r++) patch[crowoff(r, ehh) * 32 + ej] = acc[x_][y_][r];
         asm volatile("" ::: "memory");
+        if (!early) fetch_operands();
 #pragma unroll
         for (int p = 0; p < 4; p++) {
           const int row = erow + 8 * p;
@@ -480,11 +499,11 @@ __global__ __launch_bounds__(256, 5) void conv2d_f32_big2_kernel(ConvArgs a, con
           if (nn < N && m < Mg) {
             const int co = g * Mg + m;
             const size_t off = ((size_t)ob * a.Cout + co) * HoWo + op;
-            if (a.splits > 1) {                                 // raw partial sum; conv_splitk_reduce_kernel adds bias / residual / ReLU
+            if (!fin) {                                         // raw partial sum; conv_splitk_reduce_kernel adds bias / residual / ReLU
               *reinterpret_cast<f32x4 *>(a.part + part_base + off) = v;
             } else {
-              if (a.bias) { const float bv = a.bias[co]; v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv; }
-              if (a.res) { const f32x4 rv = *reinterpret_cast<const f32x4 *>(a.res + off); v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3]; }
+              v[0] += bv[p]; v[1] += bv[p]; v[2] += bv[p]; v[3] += bv[p];          // (bias, then residual: the order of the scalar path)
+              v[0] += rv[p][0]; v[1] += rv[p][1]; v[2] += rv[p][2]; v[3] += rv[p][3];
               if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
               *reinterpret_cast<f32x4 *>(a.out + ((size_t)ob * a.o_cstride + a.o_coff + co) * HoWo + op) = v;
             }
