@@ -27,4 +27,9 @@ timeout 900 python3 "$repo/tools/ab_bf16_ds.py" 512 2 2>&1 | grep -v amdgpu.ids 
 timeout 600 python3 "$repo/tools/conv_by_shape.py" 256 2>&1 | grep -v amdgpu.ids > "$repo/$out/cfg4_conv_by_shape.txt"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/cfg4_stats" -o r -- python3 "$repo/tools/run_cfg4_step.py" 256 3 > "$repo/$out/cfg4_step.log" 2>&1
 cp "$repo/$out"/cfg4_stats/*kernel_stats.csv "$repo/$out/cfg4_kernel_stats.csv" 2>/dev/null
+#   5. the "board ceiling" of both designs on THIS box: the product kernels (fused and deferred-skip, B = 256) and the synthetic mixes
+{ echo "== the product kernels, B = 256 (tools/ab_bf16_ds.py timing part)"; AP_DS_GROUPS=0,36 timeout 600 python3 "$repo/tools/ab_bf16_ds.py" 256 3 | grep -E "round|G = ";
+  hipcc --offload-arch=gfx950 -O3 "$repo/tools/micro/mfma_hbm_mix.hip" -o /tmp/mfma_hbm_mix -lpthread 2>/dev/null &&
+  { echo "== synthetic mixes, same box, 32000 tiles per launch (a 256-clip launch)"; for b in 1 2; do for m in fused ds_block ds_skip; do timeout 120 /tmp/mfma_hbm_mix 4 $b $m 0; done; done;
+    echo "== 16x16x32 in place of 32x32x16"; for m in fused ds_block; do timeout 120 /tmp/mfma_hbm_mix 4 1 $m 1; done; }; } 2>&1 | grep -v amdgpu.ids > "$repo/$out/mfma_hbm_mix.txt"
 ls "$repo/$out"

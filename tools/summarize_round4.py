@@ -109,3 +109,4 @@ for n, d in (("bench.json", "r4_bench.json"), ("bench_torchrun_n1.json", "r4_ben
         shutil.copy(os.path.join(src, n), os.path.join(P, d))
 text("ab_bf16_ds.txt", "r4_bf16_deferred_skip_ab.txt")
 text("cfg4_conv_by_shape.txt", "r4_cfg4_conv_by_shape.txt")
+text("mfma_hbm_mix.txt", "r4_mfma_hbm_mix.txt")
