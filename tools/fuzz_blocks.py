@@ -1,4 +1,4 @@
-"""Randomised hazard hunt over the four residual-block kernels: python tools/fuzz_blocks.py [cases] [seed]
+"""Randomised hazard hunt over the four residual-block kernels and the bf16 deferred-skip pair: python tools/fuzz_blocks.py [cases] [seed]
 Random batch / length (multiples of 4 and not) / layer (dilation) / accumulate flag; every mode is run twice (bit-identical
 results required, outputs inside guard bands that must stay untouched) and compared with the exact fp32 kernel (split modes 5e-6 of max, bf16 3e-2)."""
 import sys, os, numpy as np, torch
@@ -48,6 +48,22 @@ for i in range(cases):
         if not (torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()):
             print(f"NONFINITE {mode} B={B} L={L} layer={layer} acc={acc}"); bad += 1
         res[mode] = outs[0]
+    # bf16 mode's deferred-skip pair (ap_resblock_fwd_gate + ap_skip_gemm, one-layer group): h' and skip must equal the fused bf16
+    # kernel's bit for bit, twice, with every output (h', the bf16 g image, skip) inside untouched guard bands
+    eng = nets["bf16"].engine()
+    for rep in range(2):
+        G, n = 1024, h.numel()
+        hb, sb = torch.full((n + 2 * G,), 7.25, device=dev), torch.full((n + 2 * G,), 7.25, device=dev)
+        gb = torch.full((n + 2 * G,), 7.25, device=dev, dtype=torch.bfloat16)
+        ho, sk, gi = hb[G:G + n].view_as(h), sb[G:G + n].view_as(h), gb[G:G + n]
+        ho.fill_(float("nan")); sk.copy_(sk0)
+        N.check(eng.lib.ap_resblock_fwd_gate(eng.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho), gi.data_ptr(), B, L, N.stream()))
+        N.check(eng.lib.ap_skip_gemm(eng.ctx, layer, 1, gi.data_ptr(), N.ptr(sk), acc, B, L, N.stream()))
+        for nm, buf in (("h'", hb), ("skip", sb), ("g image", gb)):
+            if not (bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all())):
+                print(f"OUT-OF-BOUNDS WRITE {nm} deferred-skip B={B} L={L} layer={layer} acc={acc}"); bad += 1
+        if not (torch.equal(ho, res["bf16"][0]) and torch.equal(sk, res["bf16"][1])):
+            print(f"DEFERRED-SKIP != FUSED bf16 B={B} L={L} layer={layer} acc={acc}: h' {rel(ho, res['bf16'][0]):.2e} skip {rel(sk, res['bf16'][1]):.2e}"); bad += 1
     for mode, t in tol.items():
         e = max(rel(res[mode][0], res["f32"][0]), rel(res[mode][1], res["f32"][1]))
         worst[mode] = max(worst[mode], e)
