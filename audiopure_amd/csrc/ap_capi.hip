@@ -150,6 +150,8 @@ extern "C" int ap_profile_enable(ap_ctx *ctx, int enable) {
   return 0;
 }
 
+extern "C" int ap_profile_is_enabled(ap_ctx *ctx) { return ctx && ctx->profile ? 1 : 0; }
+
 // per kind: [0] residual-block launches, [1] skip-GEMM launches of the deferred-skip form
 static int profile_sum(ap_ctx *ctx, double ms_by_kind[2], int64_t n_by_kind[2]) {
   ms_by_kind[0] = ms_by_kind[1] = 0.0;

@@ -71,6 +71,11 @@ class _ResidualGroupParams(nn.Module):
         self.residual_blocks = nn.ModuleList([_ResidualBlockParams(C, S, Eout) for _ in range(N)])
 
 
+import itertools
+
+_ENGINE_SERIAL = itertools.count(1)
+
+
 class NativeEngine:
     """Owns the ap_ctx, the packed weights on the device and a cached workspace."""
 
@@ -82,6 +87,7 @@ class NativeEngine:
         h = C.c_void_p()
         N.check(self.lib.ap_ctx_create(C.byref(self.cfg), C.byref(h)), "ap_ctx_create")
         self.ctx = h
+        self.serial = next(_ENGINE_SERIAL)           # identity for caches that must not confuse a new engine with a collected one
         self.ws = None
         self.max_chunk = 512
         self.loaded_key = None

@@ -37,6 +37,70 @@ class DiffWave(torch.nn.Module):
         self.freeze = False
         self.grad_enable = grad_enable
         self._noise = None
+        self._graphs = {}
+
+    # ---- small batches: the chain as a replayed HIP graph ------------------------------------------------------
+    # The callers' loops run B = 1 ... 10 clips hundreds of times (adaptive_attack_eval.py:47,156-160): a chain is then
+    # 36 n + 5 n dependent launches of tens of microseconds each, and the gaps between them are a tenth of the step.
+    # The launch functions neither allocate nor synchronise (include/audiopure.h), so the whole ap_purify_chain call is
+    # captured once per (shape, coefficients, noise key) into a HIP graph on static buffers and replayed: same kernels,
+    # same arguments, same results bit for bit (tests/test_gpu_parity.py).  Off: ``dw.graph_replay = False``.
+    graph_replay = True
+    GRAPH_MAX_SAMPLES = 16 * 16000                   # clips x samples per call up to which a chain is replayed
+    GRAPH_CACHE = 8
+
+    def __getstate__(self):                          # captured graphs are rebuilt on demand, never pickled
+        d = dict(self.__dict__)
+        d["_graphs"] = {}
+        return d
+
+    def _chain_replayed(self, eng, x, steps, qa, qs, n_draws):
+        """-> purified batch through a cached graph of ONE ap_purify_chain call, or None where the call is not replayable
+        (explicit noise tensors, profiling hooks on, a capture already in progress, a batch that needs several calls)."""
+        B, _, L = x.shape
+        src = self._noise
+        if (not self.graph_replay or not steps or B < 1 or B * L > self.GRAPH_MAX_SAMPLES or B > eng.max_chunk or isinstance(src, list)
+                or torch.cuda.is_current_stream_capturing() or eng.lib.ap_profile_is_enabled(eng.ctx)):
+            return None
+        dev = x.device
+        ws = eng.workspace(B, L, dev)
+        seed, off = (src[1], src[2]) if isinstance(src, tuple) else (0, 0)
+        key = (dev.index, B, L, tuple(steps), float(qa), float(qs), n_draws, eng.serial, int(eng.skip_group or 0), ws.data_ptr(),
+               isinstance(src, tuple), seed, off)
+        ent = self._graphs.get(key)
+        self._graph_misses = 0 if ent is not None else getattr(self, "_graph_misses", 0) + 1
+        if self._graph_misses > 2 * self.GRAPH_CACHE:    # a caller whose every call differs (rand_t over a wide range): capturing
+            self.graph_replay = False                    # costs two eager runs per miss -- stay eager for this object
+            return None
+        if ent is None:
+            x_in, out = torch.empty_like(x), torch.empty_like(x)
+            z = torch.empty((n_draws, B, L), device=dev, dtype=torch.float32) if (n_draws and src is None) else None
+            arr = (N.ApStep * len(steps))(*[N.ApStep(*s) for s in steps])
+
+            def call():
+                N.check(eng.lib.ap_purify_chain(eng.ctx, N.ptr(x_in), float(qa), float(qs), arr, len(steps), N.ptr(z), seed, off,
+                                                N.ptr(out), B, L, ws.data_ptr(), ws.numel(), N.stream()), "ap_purify_chain")
+
+            x_in.copy_(x)
+            if z is not None:
+                z.zero_()
+            cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                call()                               # warm run outside the capture (first-use allocations inside torch)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                call()
+            if len(self._graphs) >= self.GRAPH_CACHE:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = (g, x_in, out, z, arr, ws)
+        g, x_in, out, z = ent[:4]
+        x_in.copy_(x)
+        if z is not None:
+            z.normal_()                              # the device generator's stream, as torch.randn in the eager path
+        g.replay()
+        return out.clone()
 
     # ---- noise plumbing ---------------------------------------------------------------------
     def set_noise_source(self, src=None):
@@ -90,6 +154,9 @@ class DiffWave(torch.nn.Module):
             return self._chain_grad(x, steps, qa, qs, n_draws)
         eng = self._tables()
         B, _, L = x.shape
+        replayed = self._chain_replayed(eng, x, steps, qa, qs, n_draws)
+        if replayed is not None:
+            return replayed
         z_all, seed, off = self._draws(n_draws, x)
         out = torch.empty_like(x)
         arr = (N.ApStep * len(steps))(*[N.ApStep(*s) for s in steps]) if steps else None

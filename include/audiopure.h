@@ -124,6 +124,7 @@ int ap_ctx_get_schedule(ap_ctx *ctx, int which, float *out_host, int n);
  * and the number of launches since ap_profile_enable, and resets the counter.  Not graph-capturable while on. */
 int ap_profile_enable(ap_ctx *ctx, int enable);
 int ap_profile_read(ap_ctx *ctx, double *total_ms, int64_t *launches);
+int ap_profile_is_enabled(ap_ctx *ctx);   /* 1 while the hook records events (the launches are then not graph-capturable) */
 /* The same reading split by kernel: [0] residual-block launches, [1] skip-GEMM launches of the deferred-skip form (whose time
  * ap_profile_read folds into total_ms while counting only the block launches, so "ms per layer" stays comparable). */
 int ap_profile_read_split(ap_ctx *ctx, double *ms_by_kind, int64_t *launches_by_kind);

@@ -755,6 +755,46 @@ def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
             assert rel_err(outs["bf16"][k], outs["f32"][k]) < 3e-2, (B, L, layer, k)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_small_batches_replay_a_captured_graph_with_identical_results(mini, dh, dev, mode):
+    """DiffWave._chain at the callers' batch sizes (adaptive_attack_eval.py:47: --batch_size 10) replays one captured
+    ap_purify_chain call per (shape, coefficients, noise key): same kernels and arguments, so the result equals the eager call's
+    bit for bit -- Philox noise, torch-generator noise under the same seed, a changed input, a changed reverse_timestep (new key);
+    explicit noise tensors, large batches and a disabled switch stay eager."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    if mode == "f32":
+        cfg, net, _ = mini
+    else:
+        net, _ = _net(synth.mini_wavenet_config(256, 12, 12), dev, seed=4)
+        net.set_precision("bf16")
+    x = torch.from_numpy(synth.waveforms(3, 2000, seed=5)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+    eager = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+    eager.graph_replay = False
+    for src in (("philox", 21, 4), None):
+        dw.set_noise_source(src)
+        eager.set_noise_source(src)
+        for k, xin in enumerate((x, x * 0.5, x)):
+            torch.manual_seed(100 + k)
+            ref = eager(xin)
+            torch.manual_seed(100 + k)
+            got = dw(xin)
+            assert torch.equal(got, ref), (mode, src, k)
+    assert len(dw._graphs) == 2 and not eager._graphs
+    dw.reverse_timestep = eager.reverse_timestep = 2             # certification changes it per call (certified_robust.py:53)
+    dw.set_noise_source(("philox", 21, 4)); eager.set_noise_source(("philox", 21, 4))
+    assert torch.equal(dw(x), eager(x)) and len(dw._graphs) == 3
+    assert torch.equal(dw.one_shot_denoise(x), eager.one_shot_denoise(x))
+    n0 = len(dw._graphs)
+    z = [torch.from_numpy(synth.noise(d, 3, 2000, seed=7)) for d in range(2)]
+    dw.set_noise_source(list(z)); eager.set_noise_source(list(z))
+    assert torch.equal(dw(x), eager(x)) and len(dw._graphs) == n0              # explicit noise tensors: eager
+    big = torch.from_numpy(synth.waveforms(20, 16000, seed=6)).to(dev)          # 20 clips of 1 s: past the replay bound
+    dw.set_noise_source(("philox", 3, 0))
+    dw(big)
+    assert len(dw._graphs) == n0
+
+
 def test_bf16_deferred_skip_chain_is_hip_graph_capturable(dh, dev):
     """The bf16 mode's two-kernel form (36 block launches + the skip GEMM per evaluation, ap_ctx_set_skip_group on the host side
     only) captures into a HIP graph like the fp32 chain does, and a replay reproduces the eager result bit for bit."""
