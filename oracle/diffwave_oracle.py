@@ -91,7 +91,41 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).float()
 
 
-def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor, bf16_operands: bool = False):
+def winograd_dilated_conv(u: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, d: int) -> torch.Tensor:
+    """The k = 3, dilation d, zero-padded conv of WaveNet.py:87 in the F(2,3) minimal-filtering form the AP_PREC_F32 HIP kernel
+    uses: outputs t and t + d share the taps u[t-d], u[t], u[t+d], u[t+2d], so the pair costs four [2C x C] products instead of
+    six.  Same operation order as the kernel: transformed weights computed in double and rounded to fp32 once, input
+    differences in fp32, fp32 products summed per component, then y0 = (m1 + m2) + m3, y1 = (m2 - m3) + m4'.
+    Samples t with floor(t / d) even are a pair's first output, the others its second."""
+    B, C, L = u.shape
+    W64 = W.double()
+    G = [W64[:, :, 0], (W64[:, :, 0] + W64[:, :, 1] + W64[:, :, 2]) / 2, (W64[:, :, 0] - W64[:, :, 1] + W64[:, :, 2]) / 2,
+         W64[:, :, 2]]
+    G = [g.float() for g in G]
+    t = torch.arange(L)
+    tf = t[(t // d) % 2 == 0]                                  # first outputs of the pairs
+
+    def tap(off):                                              # u[tf + off] with zero padding
+        idx = tf + off
+        ok = (idx >= 0) & (idx < L)
+        v = u[:, :, idx.clamp(0, L - 1)]
+        return torch.where(ok, v, torch.zeros((), dtype=u.dtype))
+
+    d0, d1, d2, d3 = tap(-d), tap(0), tap(d), tap(2 * d)
+    m1 = torch.einsum("oc,bcp->bop", G[0], d0 - d2)
+    m2 = torch.einsum("oc,bcp->bop", G[1], d1 + d2) + bias.view(1, -1, 1)
+    m3 = torch.einsum("oc,bcp->bop", G[2], d2 - d1)
+    m4 = torch.einsum("oc,bcp->bop", G[3], d3 - d1)
+    y = torch.empty(B, W.shape[0], L, dtype=u.dtype)
+    y[:, :, tf] = (m1 + m2) + m3
+    ts = tf + d
+    ok = ts < L
+    y[:, :, ts[ok]] = ((m2 - m3) + m4)[:, :, ok]
+    return y
+
+
+def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor, bf16_operands: bool = False,
+                   winograd: bool = False):
     """One ``Residual_block.forward`` (WaveNet.py:75-97).
 
     NB the reference's ``h += part_t`` aliases the block input (``h = x`` at :77,
@@ -104,8 +138,11 @@ def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.T
     B, C, L = x.shape
     part_t = F.linear(emb, w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).view(B, C, 1)    # :82-83
     u = x + part_t                                                                       # :84 (alias!)
-    h = F.conv1d(q(u), q(w[p + ".dilated_conv_layer.conv.weight"]), w[p + ".dilated_conv_layer.conv.bias"],
-                 dilation=dilation, padding=dilation)                                    # :87, :26-27
+    if winograd:
+        h = winograd_dilated_conv(u, w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"], dilation)
+    else:
+        h = F.conv1d(q(u), q(w[p + ".dilated_conv_layer.conv.weight"]), w[p + ".dilated_conv_layer.conv.bias"],
+                     dilation=dilation, padding=dilation)                                # :87, :26-27
     out = torch.tanh(h[:, :C, :]) * torch.sigmoid(h[:, C:, :])                           # :90
     res = F.conv1d(q(out), q(w[p + ".res_conv.weight"]), w[p + ".res_conv.bias"])        # :93
     skip = F.conv1d(q(out), q(w[p + ".skip_conv.weight"]), w[p + ".skip_conv.bias"])     # :95
@@ -113,7 +150,7 @@ def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.T
 
 
 def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict | None = None,
-            bf16_operands: bool = False) -> torch.Tensor:
+            bf16_operands: bool = False, winograd: bool = False) -> torch.Tensor:
     """``WaveNet_Speech_Commands.forward((audio, diffusion_steps))`` (WaveNet.py:164-172).
 
     w: folded weights (``fold_state_dict``); x: [B,1,L]; steps: float [B,1].
@@ -127,7 +164,7 @@ def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict
     emb = _swish(F.linear(emb, w["residual_layer.fc_t2.weight"], w["residual_layer.fc_t2.bias"]))   # :126
     skip = 0
     for n in range(N):                                                                   # :131-133
-        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb, bf16_operands)
+        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb, bf16_operands, winograd)
         skip = skip + skip_n
         if taps is not None:
             taps[f"h{n}"] = h
@@ -151,21 +188,22 @@ def q_sample(dh: dict, x0: torch.Tensor, t_star: int, z: torch.Tensor) -> torch.
     return torch.sqrt(ab) * x0 + torch.sqrt(1 - ab) * z                                  # :67
 
 
-def ddpm_coefficients(w, cfg, dh, x, t: int, bf16_operands: bool = False):
-    eps = eps_net(w, cfg, x, _steps(x.shape[0], t), bf16_operands=bf16_operands)         # :157-158
+def ddpm_coefficients(w, cfg, dh, x, t: int, bf16_operands: bool = False, winograd: bool = False):
+    eps = eps_net(w, cfg, x, _steps(x.shape[0], t), bf16_operands=bf16_operands, winograd=winograd)   # :157-158
     A, Ab = dh["Alpha"], dh["Alpha_bar"]
     mu = (x - (1 - A[t]) / torch.sqrt(1 - Ab[t]) * eps) / torch.sqrt(A[t])               # :159
     return eps, mu, dh["Sigma"][t]                                                       # :160
 
 
-def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list, bf16_operands: bool = False) -> torch.Tensor:
+def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list, bf16_operands: bool = False,
+                winograd: bool = False) -> torch.Tensor:
     """``DiffWave.forward`` with injected noise: noises[0] = q-sample z, noises[k] = k-th reverse draw.
     ``bf16_operands``: every eps-evaluation of the chain emulates the AP_PREC_BF16 mode (see ``residual_block``)."""
     with torch.no_grad():
         x = q_sample(dh, x0, t_star, noises[0])
         k = 1
         for t in range(t_star - 1, -1, -1):                                              # :95
-            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t, bf16_operands)
+            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t, bf16_operands, winograd)
             if t > 0:
                 x = mu + sigma * noises[k]                                               # :100
                 k += 1

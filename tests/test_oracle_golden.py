@@ -193,3 +193,35 @@ def test_oracle_fast_reverse_matches_reference(golden2, dh, mini, ts):
     x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=21))
     xr = O.fast_reverse(w, cfg, dh, x0 * 1.1, ts, _nl(3, 23))
     assert rel_err(xr.numpy(), golden2[f"mini/fast_reverse_t{ts}"]) < 1e-5
+
+
+# ---- round 5: the F(2,3) minimal-filtering form of the dilated conv (what the AP_PREC_F32 HIP block computes) ----
+def test_winograd_form_of_the_dilated_conv_is_the_conv(mini):
+    """Pair structure, padding and the four transformed products restate WaveNet.py:87 for every dilation, d >= L included."""
+    cfg, w = mini
+    p = "residual_layer.residual_blocks.0.dilated_conv_layer.conv"
+    W, b = w[p + ".weight"], w[p + ".bias"]
+    g = torch.Generator().manual_seed(5)
+    for L, d in [(1000, 1), (1000, 2), (257, 8), (1000, 64), (1000, 512), (130, 256), (77, 2048), (1, 1), (2, 1), (3, 2)]:
+        u = torch.randn(2, W.shape[1], L, generator=g)
+        ref = torch.nn.functional.conv1d(u, W, b, dilation=d, padding=d)
+        got = O.winograd_dilated_conv(u, W, b, d)
+        assert rel_err(got.numpy(), ref.numpy()) < 2e-6, (L, d)
+
+
+def test_winograd_form_holds_the_reference_golden_at_the_fp32_tolerances(golden, full, mini, dh):
+    """with the dilated conv in F(2,3) form the reference's vectors are met at the tolerances the GPU
+    tests use for the exact-fp32 block (tests/test_gpu_parity.py TOL_EVAL 2e-5, TOL_CHAIN 1e-4) -- measured 2.8e-6 / 2.8e-7."""
+    cfg, w = full
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234))
+    with torch.no_grad():
+        eps = O.eps_net(w, cfg, x0, 4.0 * torch.ones(2, 1), winograd=True)
+    assert rel_err(eps.numpy(), golden["full/eps_t4"]) < 2e-5 / 4
+    z = [torch.from_numpy(synth.noise(0, 2, 16000, seed=1234))]
+    x = O.ddpm_purify(w, cfg, dh, x0, 1, z, winograd=True)
+    assert rel_err(x.numpy(), golden["full/ddpm_n1/x"]) < 1e-4 / 4
+    cfgm, wm = mini
+    xm = torch.from_numpy(synth.waveforms(2, 4133, seed=7)) * 2.0
+    with torch.no_grad():
+        epsm = O.eps_net(wm, cfgm, xm, 3.0 * torch.ones(2, 1), winograd=True)
+    assert rel_err(epsm.numpy(), golden["mini/L4133/eps"]) < TOL_NET * 2
