@@ -62,6 +62,8 @@ SIGNATURES = {
     "ap_resblock_fwd_gate": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "ap_skip_gemm": (_i, [_vp, _i, _i, _vp, _fp, _i, _i, _i, _vp]),
     "ap_ctx_set_skip_group": (_i, [_vp, _i]),
+    "ap_ctx_set_f32_form": (_i, [_vp, _i]),
+    "ap_ctx_get_f32_form": (_i, [_vp]),
     "ap_profile_is_enabled": (_i, [_vp]),
     "ap_profile_read_split": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ap_final_affine": (_i, [_vp, _fp, _fp, _fp, _fp, _f, _f, _f, _fp, _u64, _u32, _u64, _i, _i, _vp]),

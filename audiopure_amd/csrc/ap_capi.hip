@@ -103,6 +103,9 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->w1p_bf = c->w2p_bf = c->wf1p_bf = c->w1q_bf = nullptr;
   c->slab_s = nullptr;
   c->slab_h = nullptr;
+  c->slab_w = nullptr;
+  c->w1w = c->w2w = nullptr;
+  c->f32_form = 1;
   c->w1p_h = c->w2p_h = nullptr;
   c->w1p_s = c->w2p_s = nullptr;
   c->profile = false;
@@ -138,6 +141,7 @@ extern "C" int ap_ctx_destroy(ap_ctx *ctx) {
   if (ctx->slab_bf) (void)hipFree(ctx->slab_bf);
   if (ctx->slab_s) (void)hipFree(ctx->slab_s);
   if (ctx->slab_h) (void)hipFree(ctx->slab_h);
+  if (ctx->slab_w) (void)hipFree(ctx->slab_w);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
@@ -193,6 +197,18 @@ extern "C" int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group) {
   }
   ctx->skip_group = layers_per_group;
   return 0;
+}
+
+extern "C" int ap_ctx_set_f32_form(ap_ctx *ctx, int form) {
+  if (!ctx) { set_error("ap_ctx_set_f32_form: null ctx"); return -22; }
+  if (form != 0 && form != 1) { set_error("ap_ctx_set_f32_form: form %d (0 direct, 1 minimal-filtering)", form); return -22; }
+  if (ctx->cfg.precision != AP_PREC_F32) { set_error("ap_ctx_set_f32_form: AP_PREC_F32 contexts only"); return -22; }
+  ctx->f32_form = form;
+  return 0;
+}
+
+extern "C" int ap_ctx_get_f32_form(ap_ctx *ctx) {
+  return ctx && ctx->cfg.precision == AP_PREC_F32 && ctx->f32_form == 1 && ctx->C == 256 && ctx->S == 256 ? 1 : 0;
 }
 
 extern "C" int ap_ctx_set_schedule(ap_ctx *ctx, const float *beta, const float *alpha, const float *alpha_bar,
@@ -280,6 +296,16 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
 #endif
     }
     rc = launch_pack_bf16(ctx, st);
+    if (rc) return rc;
+  }
+  if (c.precision == AP_PREC_F32 && C == 256 && S == 256) {
+    const size_t n1w = NL * 4 * 2 * C * C, n2 = NL * (C + S) * C;
+    if (!ctx->slab_w) {
+      AP_HIP(hipMalloc(&ctx->slab_w, (n1w + n2) * sizeof(float)));
+      ctx->w1w = (float *)ctx->slab_w;
+      ctx->w2w = ctx->w1w + n1w;
+    }
+    rc = launch_pack_f32w(ctx, st);
     if (rc) return rc;
   }
   if (c.precision == AP_PREC_F32_SPLIT) {
@@ -439,8 +465,11 @@ int run_net(ap_ctx *ctx, const float *x, float step, const Ws &w, int B, int L, 
     }
     return 0;
   }
+  // (the last layer's h' is never read -- WaveNet.py:131-135 returns the skip sum only; the minimal-filtering block leaves
+  // res_conv and its store out when handed a null h')
+  const bool drop_last = resblock_f32w_serves(ctx, B, L);
   for (int n = 0; n < ctx->NL; n++) {
-    rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, hout, w.skip, n > 0, B, L, st);
+    rc = launch_resblock(ctx, n, hin, w.pt + (size_t)n * ctx->C, (drop_last && n + 1 == ctx->NL) ? nullptr : hout, w.skip, n > 0, B, L, st);
     if (rc) return rc;
     float *t = hin; hin = hout; hout = t;
   }

@@ -83,6 +83,9 @@ struct ap_ctx {
   void *slab_s;
   void *w1p_h, *w2p_h;      // 2-way fp16-split images (AP_PREC_F32_SPLIT_F16), own allocation
   void *slab_h;
+  float *w1w, *w2w;         // AP_PREC_F32, C = S = 256: F(2,3)-transformed GEMM1 image and GEMM2 image of ap_resblock_f32w.hip, own allocation
+  void *slab_w;
+  int f32_form;             // AP_PREC_F32: 1 = minimal-filtering (Winograd) block where built (default), 0 = direct-form block
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
   bool profile;
@@ -102,6 +105,29 @@ struct ap_m5 {
 // kernel launchers (defined in the .hip files)
 #ifdef __HIPCC__
 namespace ap {
+// row of accumulator register r of a 32x32 MFMA tile held by lane half hh
+__device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// exp(x) on the hardware exp2 with a compensated argument: ~2 ulp over the range the gate uses.
+__device__ __forceinline__ float exp_acc(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
+  const float L2E_LO = 1.92596299e-8f;               // log2 e - L2E_HI
+  float t = x * L2E_HI;
+  float r = __builtin_fmaf(x, L2E_HI, -t);
+  r = __builtin_fmaf(x, L2E_LO, r);
+  float e = __builtin_amdgcn_exp2f(t);
+  return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
+}
+
+// tanh(a) * sigmoid(b) = (E - 1) / ((E + 1) (1 + F)),  E = e^{2a}, F = e^{-b}   (WaveNet.py:90)
+__device__ __forceinline__ float gate(float a, float b) {
+  a = fminf(fmaxf(a, -15.0f), 15.0f);    // tanh(+-15) == +-1 in fp32
+  b = fmaxf(b, -80.0f);                  // keep F finite: sigmoid(-80) ~ 1.8e-35
+  float E = exp_acc(2.0f * a);
+  float F = exp_acc(-b);
+  return (E - 1.0f) * __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
+}
+
 // Which (clip, tile) a workgroup of a one-tile-per-workgroup block kernel takes.  Placement only -- any bijection gives the same
 // results; this one is for the per-XCD L2s: workgroups b, b + 8, ... share an XCD (round-robin dispatch), so each XCD takes a
 // contiguous run of (clip, position) work, and inside a clip position p maps to tile r + k s (residue classes r = 0 .. s-1 in
@@ -156,6 +182,10 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 int launch_skipgemm_bf16(ap_ctx *ctx, int layer0, int nl, const void *gimg, float *skip, int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_bf16w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);   // one wave per SIMD; returns 1 if the shape is not served
+int launch_pack_f32w(ap_ctx *ctx, hipStream_t st);
+bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L);       // AP_PREC_F32 in minimal-filtering form, and this shape is built
+int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
+                         int accumulate, int B, int L, hipStream_t st);   // hout null: the net's last layer (no res_conv, no h'); returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
 int launch_pack_splith(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,

@@ -10,28 +10,6 @@
 
 namespace ap {
 
-__device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
-
-// exp(x) on the hardware exp2 with a compensated argument: ~2 ulp over the range the gate uses.
-__device__ __forceinline__ float exp_acc(float x) {
-  const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
-  const float L2E_LO = 1.92596299e-8f;               // log2 e - L2E_HI
-  float t = x * L2E_HI;
-  float r = __builtin_fmaf(x, L2E_HI, -t);
-  r = __builtin_fmaf(x, L2E_LO, r);
-  float e = __builtin_amdgcn_exp2f(t);
-  return __builtin_fmaf(e, r * 0.693147182464599609375f, e);
-}
-
-// tanh(a) * sigmoid(b) = (E - 1) / ((E + 1) (1 + F)),  E = e^{2a}, F = e^{-b}   (WaveNet.py:90)
-__device__ __forceinline__ float gate(float a, float b) {
-  a = fminf(fmaxf(a, -15.0f), 15.0f);    // tanh(+-15) == +-1 in fp32
-  b = fmaxf(b, -80.0f);                  // keep F finite: sigmoid(-80) ~ 1.8e-35
-  float E = exp_acc(2.0f * a);
-  float F = exp_acc(-b);
-  return (E - 1.0f) * __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
-}
-
 // ---------------------------------------------------------------------------------------------
 // weight-norm fold (WaveNet.py:23-34; nn.utils.weight_norm dim=0) and MFMA operand packing
 // ---------------------------------------------------------------------------------------------
@@ -523,6 +501,7 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
 }
 
 AP_TOOLS_VAR g_tile = 64;    // time tile of the residual-block kernel: 64 (4 waves, 2 WG/CU); 128 (8 waves, 1 WG/CU) in tools builds
+AP_TOOLS_VAR g_force_direct = 0;   // tools builds: the direct-form fp32 block even where the minimal-filtering one is built
 AP_TOOLS_VAR g_force_f32 = 0;  // tools builds: run the fp32 kernel even in a bf16 context (A/B timing in one process)
 #ifdef AP_TOOLS
 static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
@@ -564,6 +543,30 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   }
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
+  if (!aout && !g_force_direct && resblock_f32w_serves(ctx, B, L)) {     // F(2,3) form of the dilated conv (ap_resblock_f32w.hip)
+    hipEvent_t w0 = nullptr, w1e = nullptr;
+    if (ctx->profile) {
+      if (ctx->ev_used + 2 > ctx->ev.size())
+        for (int i = 0; i < 2; i++) {
+          hipEvent_t e;
+          AP_HIP(hipEventCreate(&e));
+          ctx->ev.push_back(e);
+        }
+      w0 = ctx->ev[ctx->ev_used];
+      w1e = ctx->ev[ctx->ev_used + 1];
+      if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
+      ctx->ev_kind[ctx->ev_used / 2] = 0;
+      ctx->ev_used += 2;
+      AP_HIP(hipEventRecord(w0, st));
+    }
+    const int rcw = launch_resblock_f32w(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+    if (w1e) AP_HIP(hipEventRecord(w1e, st));
+    return rcw;
+  }
+  if (!hout) {
+    set_error("resblock: the direct-form block needs an h' buffer");
+    return -22;
+  }
   const float *w1p = ctx->w1p + (size_t)layer * 2 * C * C * 3;
   const float *w2p = ctx->w2p + (size_t)layer * (C + S) * C;
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;

@@ -44,7 +44,6 @@ constexpr int XS_ = 3 * KC_ + 8;         // bf16 per column row of the X image (
 constexpr int GS_ = 256 + 8;             // bf16 per column row of the g image (528 B)
 constexpr int PS_ = 32;                  // fp32 per row of the wave-private output patch (128 B)
 
-__device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // tanh(a) sigmoid(b) = (1 - E) / ((1 + E)(1 + F)), E = e^(-2a), F = e^(-b).  a is clamped to [-16, 16] first (one v_med3;
 // tanh(+-16) rounds to +-1 in fp32, so the clamp changes no result): E stays finite, the sign comes out of 1 - E, and no

@@ -189,6 +189,15 @@ int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, fl
                  int B, int L, void *stream);
 int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group);
 
+/* AP_PREC_F32 arithmetic form of the dilated conv (WaveNet.py:87).  1 (default where built: res = skip = 256 channels): the
+ * F(2,3) minimal-filtering form over the dilation pair -- outputs t and t + d share their four taps, so the pair costs four
+ * [2C x C] products instead of six (block: 12.58 GFLOP per clip instead of 16.78) on the exact-fp32 matrix instruction;
+ * transformed weights are computed in double at load, results differ from the direct form by fp32 rounding only and meet the
+ * same tolerances against the reference's vectors.  0: the direct form (every other shape always runs it).
+ * ap_ctx_get_f32_form returns the form the block launches of this context will use. */
+int ap_ctx_set_f32_form(ap_ctx *ctx, int form);
+int ap_ctx_get_f32_form(ap_ctx *ctx);
+
 /* ap_resblock_fwd_save: ap_resblock_fwd that also writes the pre-gate activations y = DilConv(u) + b (WaveNet.py:87) to
  * pre_gate [B][2C][L] (rows 0..C-1 the tanh half, C..2C-1 the sigmoid half): what the backward of :90 needs, kept by the
  * differentiable purifier (the reference's autograd keeps it too) so that the adjoint does not recompute the dilated conv.

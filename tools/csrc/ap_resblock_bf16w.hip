@@ -43,7 +43,6 @@ constexpr int XS_ = 3 * KC_ + 8;         // bf16 per column row of the X image (
 constexpr int GS_ = 256 + 8;             // bf16 per column row of the g image (528 B)
 constexpr int PS_ = 32;                  // fp32 per row of the wave-private output patch (128 B)
 
-__device__ __forceinline__ int rowoff(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // the gate of ap_resblock_bf16p.hip, element for element (bit-identical kernels)
 __device__ __forceinline__ f32x2 gate_fast2(f32x2 a, f32x2 b) {
