@@ -203,15 +203,16 @@ def use_conv_workspace(device) -> None:
     """Register this device's split-K workspace with the library (``ap_conv2d_set_workspace``: one slot per HIP device, keyed by
     the device current at the call and at each launch; allocated once per device by torch's caching allocator and kept alive
     here -- the library itself allocates nothing).  Called at the entry of every native conv-net forward and of the 1-D
-    backward GEMMs; a no-op once the device has its buffer."""
+    backward GEMMs; allocates once, registers every time."""
     import torch
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx in _CONV_WS:
-        return
     with torch.cuda.device(idx):
-        ws = torch.empty(CONV_WS_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+        ws = _CONV_WS.get(idx)
+        if ws is None:
+            ws = _CONV_WS[idx] = torch.empty(CONV_WS_BYTES // 4, dtype=torch.float32, device=torch.device("cuda", idx))
+        # registered on EVERY call (one cheap ctypes call): the library's per-device slot can be cleared behind this cache
+        # (ap_conv2d_set_workspace(NULL, 0)), and split-K must not then stay off for the rest of the process
         check(lib().ap_conv2d_set_workspace(ws.data_ptr(), CONV_WS_BYTES), "ap_conv2d_set_workspace")
-    _CONV_WS[idx] = ws
 
 
 def stream() -> int:

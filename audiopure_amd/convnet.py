@@ -89,6 +89,13 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
+def _need(cond, what: str) -> None:
+    """A pattern the library has no kernel for is a ``NotImplementedError`` -- the one failure ``NativeConvNet`` may answer by
+    leaving the caller's module as it is (and only outside AUDIOPURE_STRICT); everything else propagates."""
+    if not cond:
+        raise NotImplementedError("convnet lowering: " + what)
+
+
 def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
     """Record one eval forward of `module` on a CPU example [2, C, H, W] and turn it into a Plan."""
     m = copy.deepcopy(module).to("cpu").float().eval()
@@ -126,9 +133,9 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
             vals[id(out if not isinstance(out, tuple) else out[0])] = get(src)
         elif op == "convolution":
             xin, w, b, stride, padding, dilation, transposed, _, groups = args[:9]
-            assert not transposed and tuple(dilation) == (1, 1), "dilated / transposed conv2d not lowered"
+            _need(not transposed and tuple(dilation) == (1, 1), "dilated / transposed conv2d not lowered")
             s, p_ = _pair(stride), _pair(padding)
-            assert s[0] == s[1] and p_[0] == p_[1], "anisotropic stride / padding not lowered"
+            _need(s[0] == s[1] and p_[0] == p_[1], "anisotropic stride / padding not lowered")
             v = get(xin)
             o = plan.new_buf(out.shape[1], out.shape[2], out.shape[3])
             plan.steps.append(Step("conv", o, [v], dict(w=w.detach().float(), b=None if b is None else b.detach().float(),
@@ -152,14 +159,14 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
             vals[id(out)] = o                       # relu_ returns its (mutated) input: later uses see the new value
         elif op in ("add", "add_"):
             a, b = get(args[0]), get(args[1])
-            assert kwargs.get("alpha", 1) == 1 and isinstance(a, Val) and isinstance(b, Val)
-            assert (a.C, a.H, a.W) == (b.C, b.H, b.W)
+            _need(kwargs.get("alpha", 1) == 1 and isinstance(a, Val) and isinstance(b, Val), "shape / argument pattern not lowered")
+            _need((a.C, a.H, a.W) == (b.C, b.H, b.W), "shape / argument pattern not lowered")
             o = plan.new_buf(a.C, a.H, a.W)
             plan.steps.append(Step("add", o, [a, b], dict(relu=False)))
             vals[id(out)] = o
         elif op == "cat":
             ts, dim = args[0], (args[1] if len(args) > 1 else 0)
-            assert dim == 1, "only channel concatenation is lowered"
+            _need(dim == 1, "only channel concatenation is lowered")
             vs = [get(t) for t in ts]
             o = plan.new_buf(sum(v.C for v in vs), vs[0].H, vs[0].W)
             off = 0
@@ -177,15 +184,15 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
             if dim == 0 or (start == 0 and end >= xin.shape[dim]):
                 vals[id(out)] = v
             else:
-                assert dim == 1 and step == 1 and isinstance(v, Val), "only channel slices are lowered"
+                _need(dim == 1 and step == 1 and isinstance(v, Val), "only channel slices are lowered")
                 vals[id(out)] = Val(v.buf, end - start, v.H, v.W, v.cstride, v.coff + start)
         elif op in ("max_pool2d_with_indices", "max_pool2d", "avg_pool2d"):
             xin, k = args[0], _pair(args[1])
             stride = _pair(args[2]) if len(args) > 2 and args[2] else k
             pad = _pair(args[3]) if len(args) > 3 else (0, 0)
-            assert k[0] == k[1] and stride[0] == stride[1] and pad[0] == pad[1]
+            _need(k[0] == k[1] and stride[0] == stride[1] and pad[0] == pad[1], "shape / argument pattern not lowered")
             if op == "avg_pool2d":
-                assert pad[0] == 0 or (len(args) <= 5 or args[5]), "count_include_pad=False not lowered"
+                _need(pad[0] == 0 or (len(args) <= 5 or args[5]), "count_include_pad=False not lowered")
             v = get(xin)
             if not v.full:
                 c = plan.new_buf(v.C, v.H, v.W)
@@ -199,10 +206,10 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
             v = get(args[0])
             if op == "mean":
                 dims = sorted(d % 4 for d in args[1])
-                assert dims == [2, 3], "only spatial means are lowered"
+                _need(dims == [2, 3], "only spatial means are lowered")
             else:
-                assert _pair(args[1]) == (1, 1)
-            assert v.H == v.W
+                _need(_pair(args[1]) == (1, 1), "shape / argument pattern not lowered")
+            _need(v.H == v.W, "shape / argument pattern not lowered")
             if not v.full:
                 c = plan.new_buf(v.C, v.H, v.W)
                 plan.steps.append(Step("copy", c, [v]))
@@ -216,7 +223,7 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
                 vals[id(out)] = v
                 continue
             n_el = v.C * v.H * v.W
-            assert out.numel() == 2 * n_el, "views that mix the batch axis are not lowered"
+            _need(out.numel() == 2 * n_el, "views that mix the batch axis are not lowered")
             if not v.full:
                 c = plan.new_buf(v.C, v.H, v.W)
                 plan.steps.append(Step("copy", c, [v]))
@@ -231,15 +238,15 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
             if op == "addmm":
                 b, xin, wt = args[0], args[1], args[2]
                 kind, w = get(wt)
-                assert kind == "paramT"
+                _need(kind == "paramT", "shape / argument pattern not lowered")
             elif op == "mm":
                 b, xin = None, args[0]
                 kind, w = get(args[1])
-                assert kind == "paramT"
+                _need(kind == "paramT", "shape / argument pattern not lowered")
             else:
                 xin, w, b = args[0], args[1], (args[2] if len(args) > 2 else None)
             v = get(xin)
-            assert v.H == 1 and v.W == 1 and v.full
+            _need(v.H == 1 and v.W == 1 and v.full, "shape / argument pattern not lowered")
             o = plan.new_buf(w.shape[0], 1, 1)
             plan.steps.append(Step("conv", o, [v], dict(w=w.detach().float().reshape(w.shape[0], w.shape[1], 1, 1),
                                                         b=None if b is None else b.detach().float(), stride=1, pad=0,
@@ -250,7 +257,7 @@ def lower(module: nn.Module, example_chw=(1, 32, 32)) -> Plan:
         else:
             raise NotImplementedError(f"convnet lowering: ATen op '{op}' is not supported")
     plan.output = get(y)
-    assert isinstance(plan.output, Val)
+    _need(isinstance(plan.output, Val), "shape / argument pattern not lowered")
     _fuse(plan)
     for st in plan.steps:
         if st.kind == "conv":
@@ -338,6 +345,12 @@ class _ConvNetInputGrad(torch.autograd.Function):
         return dx, None
 
 
+def strict() -> bool:
+    """``AUDIOPURE_STRICT=1``: the off-native routes of ``NativeConvNet.forward`` raise instead of running PyTorch operators."""
+    import os
+    return os.environ.get("AUDIOPURE_STRICT", "0") not in ("", "0")
+
+
 class NativeConvNet(nn.Module):
     """``NativeConvNet(module)(x)`` == ``module.eval()(x)`` for the reference's 2-D classifiers, computed by the HIP
     library.  The wrapped module keeps owning the parameters (``.module``); call ``refresh()`` after changing them."""
@@ -398,12 +411,21 @@ class NativeConvNet(nn.Module):
 
     _foreign = False                           # set when a lazily lowered module turns out not to be a ConvNet this library knows
 
+    def _off_native(self, x, why: str):
+        """The ONLY place a caller's module runs on PyTorch operators.  ``AUDIOPURE_STRICT=1`` (the default of tests/ and bench.py)
+        turns every such route into an error, so a lowering bug can never pass for the native path."""
+        if strict():
+            raise N.NativeError(f"{type(self.module).__name__}: {why}; AUDIOPURE_STRICT=1 forbids running the caller's module "
+                                "on PyTorch operators")
+        return self.module(x)
+
     def forward(self, x):
         """A module that ``lower_classifier`` wrapped on sight (``input_chw=None``) is only KNOWN to contain Conv2d layers.
-        What the reference's scripts would have done with it stays possible: in ``train()`` mode (BatchNorm statistics
-        live: nothing to fold), on CPU with CPU parameters, or once its trace meets an operator the library has no
-        kernel for, the caller's own module runs as it is -- said once, never silently mixed with the native path.
-        An explicitly constructed ``NativeConvNet(module, chw)`` lowers in ``__init__`` and raises there instead."""
+        What the reference's scripts would have done with it stays possible in three named cases -- ``train()`` mode (BatchNorm
+        statistics live: nothing to fold), a CPU module fed CPU tensors, and a trace that meets an operator the library has no
+        kernel for (``lower`` raises ``NotImplementedError``; any other failure of the lowering propagates) -- each said once with
+        a ``RuntimeWarning`` and each an error under ``AUDIOPURE_STRICT=1``.  An explicitly constructed
+        ``NativeConvNet(module, chw)`` lowers in ``__init__`` and raises there instead."""
         if self.training and not self._foreign:
             if not getattr(self, "_warned_train", False):
                 import warnings
@@ -411,11 +433,11 @@ class NativeConvNet(nn.Module):
                               "native plan is re-lowered from the parameters at the next eval() forward", RuntimeWarning, stacklevel=2)
                 self._warned_train = True
             self.plan, self._dev_weights = None, None            # the plan holds weights folded at lowering: stale after a training step
-            return self.module(x)
+            return self._off_native(x, "train() mode")
         if self._foreign:
-            return self.module(x)
+            return self._off_native(x, "not lowered (an operator without a kernel)")
         if not x.is_cuda and self.plan is None and all(not p.is_cuda for p in self.module.parameters()):
-            return self.module(x)
+            return self._off_native(x, "CPU module and CPU input")
         return self._forward_native(x)
 
     @N.on_device
@@ -425,14 +447,18 @@ class NativeConvNet(nn.Module):
                 self.input_chw = tuple(x.shape[1:])
                 self.plan = lower(self.module, self.input_chw)
                 self._dev_weights = None
-            except (NotImplementedError, RuntimeError, TypeError, ValueError, KeyError, IndexError, AttributeError) as e:
-                import warnings                                  # (a trace can fail in other ways than "no kernel for this operator")
+            except NotImplementedError as e:                     # "no kernel for this operator" -- nothing else is caught: an OOM, a
+                import warnings                                  # NativeError or a bug in the lowering must not latch a silent fallback
+                self.plan, self.input_chw = None, None
+                if strict():
+                    raise
                 warnings.warn(f"{type(self.module).__name__}: not lowered onto the HIP library ({e}); the module runs as "
                               "the caller built it (PyTorch operators)", RuntimeWarning, stacklevel=3)
-                self._foreign, self.plan, self.input_chw = True, None, None
+                self._foreign = True
                 return self.module(x)
         if torch.is_grad_enabled() and x.requires_grad:
             return _ConvNetInputGrad.apply(x, self)              # white-box attack: dL/dx (parameters frozen)
+        self.native_calls = getattr(self, "native_calls", 0) + 1
         return self._run(x)[0]
 
     def _run(self, x):

@@ -262,7 +262,8 @@ int launch_skipgemm_bf16(ap_ctx *ctx, int layer0, int nl, const void *gimg, floa
   const int C = ctx->C, S = ctx->S;
   if (C != 256 || S != 256 || !ctx->w2p_bf) { set_error("skip GEMM: AP_PREC_BF16 context with res = skip = 256 channels only"); return -22; }
   if (nl < 1 || layer0 < 0 || layer0 + nl > ctx->NL || B < 1 || L < 1) { set_error("skip GEMM: layers [%d, %d) B=%d L=%d", layer0, layer0 + nl, B, L); return -22; }
-  if ((size_t)L * 512 >= ((size_t)1 << 31)) { set_error("skip GEMM: clip too long for the bf16 g image"); return -22; }
+  // (1024 L: a clip's fp32 skip rows -- the out-of-clip sentinel offset 0x80000000 of the epilogue must lie beyond them)
+  if ((size_t)L * 1024 >= ((size_t)1 << 31)) { set_error("skip GEMM: clip too long (L * 1024 bytes of skip rows per clip must stay below 2^31)"); return -22; }
   static int n_cu_of[64] = {0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;

@@ -165,6 +165,7 @@ class NativeEngine:
 class WaveNet_Speech_Commands(nn.Module):
     _engine = None                             # class-level defaults: survive copy / un-pickling without __init__
     _precision = N.AP_PREC_F32
+    _f32_form = 1                              # AP_PREC_F32: 1 = minimal-filtering (F(2,3)) form of the dilated conv where built, 0 = direct
 
     def __getstate__(self):                    # the native context (device weights, workspace) is rebuilt on demand
         d = dict(self.__dict__)
@@ -195,14 +196,16 @@ class WaveNet_Speech_Commands(nn.Module):
 
     # ---- native plumbing ------------------------------------------------------------------
     def set_precision(self, mode: str):
-        """"f32": exact fp32 MFMA (default, the reference's arithmetic).  "f32s": fp32 operands split exactly into three
+        """"f32": exact fp32 MFMA (default, the reference's arithmetic); at res = skip = 256 channels the dilated conv runs in its
+        F(2,3) minimal-filtering form (include/audiopure.h: ap_ctx_set_f32_form), "f32d" keeps the direct form.  "f32s": fp32 operands split exactly into three
         bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results, ~2x faster.
         "f32h": fp32 operands carried as two fp16 parts (22 significant bits), three partial products on the fp16 MFMA,
         fp32 accumulate -- fp32-class results, ~2x faster again.
         "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  All but "f32" need
         res_channels = 256."""
-        prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
+        prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "f32d": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
                 "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "f32h": N.AP_PREC_F32_SPLIT_F16}[mode]
+        self._f32_form = 0 if mode == "f32d" else 1
         if prec != self._precision:
             self._precision = prec
             self._engine = None
@@ -236,6 +239,8 @@ class WaveNet_Speech_Commands(nn.Module):
                 freq = embedding_frequencies(self.config["diffusion_step_embed_dim_in"]).to(dev).contiguous()
                 self._engine.load(blob, freq)
             self._engine.loaded_key = key
+        if self._precision == N.AP_PREC_F32:
+            N.check(self._engine.lib.ap_ctx_set_f32_form(self._engine.ctx, int(self._f32_form)), "ap_ctx_set_f32_form")
         return self._engine
 
     @staticmethod

@@ -65,8 +65,14 @@ class DiffWave(torch.nn.Module):
         dev = x.device
         ws = eng.workspace(B, L, dev)
         seed, off = (src[1], src[2]) if isinstance(src, tuple) else (0, 0)
+        # hygiene: a graph holds raw pointers into the engine's weights and into the workspace it was captured on.  Entries of another
+        # engine (set_precision / a rebuilt engine: new serial) or of a workspace the engine has since replaced (a larger batch came
+        # by) are dropped here, so the cache never replays into freed memory and never pins more than the ONE current workspace.
+        stale = [k for k, e in self._graphs.items() if k[7] != eng.serial or e[5] is not ws]
+        for k in stale:
+            del self._graphs[k]
         key = (dev.index, B, L, tuple(steps), float(qa), float(qs), n_draws, eng.serial, int(eng.skip_group or 0), ws.data_ptr(),
-               isinstance(src, tuple), seed, off)
+               isinstance(src, tuple), seed, off, int(eng.lib.ap_ctx_get_f32_form(eng.ctx)))
         ent = self._graphs.get(key)
         self._graph_misses = 0 if ent is not None else getattr(self, "_graph_misses", 0) + 1
         if self._graph_misses > 2 * self.GRAPH_CACHE:    # a caller whose every call differs (rand_t over a wide range): capturing
@@ -81,17 +87,26 @@ class DiffWave(torch.nn.Module):
                 N.check(eng.lib.ap_purify_chain(eng.ctx, N.ptr(x_in), float(qa), float(qs), arr, len(steps), N.ptr(z), seed, off,
                                                 N.ptr(out), B, L, ws.data_ptr(), ws.numel(), N.stream()), "ap_purify_chain")
 
-            x_in.copy_(x)
-            if z is not None:
-                z.zero_()
-            cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                call()                               # warm run outside the capture (first-use allocations inside torch)
-            cur.wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                call()
+            try:
+                x_in.copy_(x)
+                if z is not None:
+                    z.zero_()
+                cur, side = torch.cuda.current_stream(dev), torch.cuda.Stream(dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    call()                           # warm run outside the capture (first-use allocations inside torch)
+                cur.wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                # thread_local: another host thread's HIP calls (a DataLoader's pin-memory thread) do not invalidate this capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    call()
+            except Exception as e:                   # a failed capture must never fail a plain dw(x): this object stays eager
+                import warnings
+                self.graph_replay = False
+                self._graphs.clear()
+                warnings.warn(f"DiffWave: HIP-graph capture of the chain failed ({type(e).__name__}: {e}); this object runs its "
+                              "chains eagerly from now on (same kernels, same results)", stacklevel=3)
+                return None
             if len(self._graphs) >= self.GRAPH_CACHE:
                 self._graphs.pop(next(iter(self._graphs)))
             ent = self._graphs[key] = (g, x_in, out, z, arr, ws)

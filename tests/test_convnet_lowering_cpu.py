@@ -141,13 +141,17 @@ def test_mel_front_end_with_other_band_or_framing_is_left_alone():
         assert lower_transform(t) is t, kw
 
 
-def test_lazily_wrapped_module_keeps_the_callers_semantics_off_the_native_path():
+def test_lazily_wrapped_module_keeps_the_callers_semantics_off_the_native_path(monkeypatch):
     """lower_classifier wraps any Conv2d-bearing module on sight; in train() mode and on CPU (CPU parameters, CPU input)
-    the wrapper runs the module itself, as the reference's scripts would have (acoustic_system.py:35-51)."""
+    the wrapper runs the module itself, as the reference's scripts would have (acoustic_system.py:35-51) -- outside
+    AUDIOPURE_STRICT, and said with a RuntimeWarning."""
+    import warnings
     import torch
     import torch.nn as nn
     from audiopure_amd.convnet import NativeConvNet
     from audiopure_amd.lowering import lower_classifier
+    monkeypatch.setenv("AUDIOPURE_STRICT", "0")
+    warnings.filterwarnings("ignore", message=".*PyTorch operators.*", category=RuntimeWarning)
     torch.manual_seed(0)
     m = nn.Sequential(nn.Conv2d(1, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
                       nn.Linear(4, 3))
@@ -158,3 +162,30 @@ def test_lazily_wrapped_module_keeps_the_callers_semantics_off_the_native_path()
     w.eval()
     with torch.no_grad():
         assert torch.equal(w(x), m(x))                                        # CPU module + CPU input: the module itself
+
+
+def test_strict_mode_turns_every_route_off_the_native_path_into_an_error(monkeypatch):
+    """under AUDIOPURE_STRICT=1 (the suite's and bench.py's default) train() mode and a CPU module raise instead
+    of running the caller's module on PyTorch operators, and a lowering failure that is not "no kernel for this operator"
+    is never caught."""
+    import torch
+    import torch.nn as nn
+    from audiopure_amd import _native as N
+    from audiopure_amd import convnet
+    from audiopure_amd.lowering import lower_classifier
+    monkeypatch.setenv("AUDIOPURE_STRICT", "1")
+    assert convnet.strict()
+    m = nn.Sequential(nn.Conv2d(1, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten(),
+                      nn.Linear(4, 3))
+    x = torch.randn(2, 1, 8, 8)
+    w = lower_classifier(m.train())
+    with pytest.raises((N.NativeError, RuntimeWarning)):
+        w(x)
+    w.eval()
+    with pytest.raises(N.NativeError, match="AUDIOPURE_STRICT"):
+        w(x)
+    # patterns without a kernel are NotImplementedError (the only failure the lazy wrapper may answer with the caller's module)
+    with pytest.raises(NotImplementedError):
+        convnet.lower(nn.Sequential(nn.Conv2d(1, 4, 3, dilation=2), nn.AdaptiveAvgPool2d(1), nn.Flatten()), (1, 8, 8))
+    with pytest.raises(NotImplementedError):
+        convnet.lower(nn.Sequential(nn.Conv2d(1, 4, 3), nn.GELU(), nn.AdaptiveAvgPool2d(1), nn.Flatten()), (1, 8, 8))

@@ -47,6 +47,32 @@ def test_full_models_match_reference_golden(dev, gold, name):
     assert rel_err(y5, ref5) < TOL
 
 
+@pytest.mark.parametrize("name", sorted(FAMILIES))
+def test_lazily_wrapped_families_run_on_the_hip_kernels(dev, gold, name):
+    """the route the eval scripts take -- a module wrapped on sight by lower_classifier (input shape unknown
+    until the first call) -- ran NATIVELY for every family: conv launches counted by the library's own hook, the same logits
+    as the reference's classes, no fallback warning (an error in this suite) and no fallback under AUDIOPURE_STRICT."""
+    import ctypes as C
+    from audiopure_amd import _native as N
+    from audiopure_amd.lowering import lower_classifier
+    lib = N.lib()
+    m = synth_init(FAMILIES[name](), 0).to(dev).eval()
+    net = lower_classifier(m)
+    assert isinstance(net, NativeConvNet) and net.plan is None
+    N.check(lib.ap_conv_profile_enable(1))
+    try:
+        y = net(_x().to(dev))
+        torch.cuda.synchronize()
+        ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
+        N.check(lib.ap_conv_profile_read(ms, fl, n, 8))
+    finally:
+        N.check(lib.ap_conv_profile_enable(0))
+    n_conv = sum(1 for st in net.plan.steps if st.kind == "conv")
+    assert net.plan is not None and not net._foreign and net.native_calls == 1
+    assert sum(n) >= n_conv > 0, (list(n), n_conv)
+    assert rel_err(y.cpu().numpy(), gold[f"{name}/logits"]) < TOL
+
+
 def test_family_structures_match_module(dev):
     from test_convnet_lowering_cpu import DenseDPN
     m = synth_init(DenseDPN(), 2)

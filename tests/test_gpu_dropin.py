@@ -396,3 +396,32 @@ def test_rev_diffwave_args_constructor_from_files_matches_sde_oracle(dev, tmp_pa
     ref = O.sde_purify(w, cfg, O.sde_tables(), x0, 4, z)
     assert got.shape == x0.shape
     assert rel_err(got.cpu().numpy(), ref.numpy()) < TOL_CHAIN
+
+
+# ---- multi-GPU readiness: exercised by GPUTEST the day the box has two devices ---------------------------------
+def test_two_rank_bench_over_rccl_reproduces_the_single_process_scores():
+    """`python bench.py --gpus 2` as the driver runs it: the launcher starts two ranks as child processes (before anything touches
+    a GPU, no re-exec), RCCL forms a 2-rank group, each rank binds its own device, and the gathered [16, 10] scores equal the
+    single-process run's on the same global batch (inputs and Philox noise are keyed on the global utterance index).  Skipped
+    on a one-GPU box -- which is every box this suite has seen so far."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs on the node (torch.cuda.device_count() < 2)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    common = ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-other-modes", "--no-other-configs", "--no-caller-shapes"]
+
+    def run(gpus, batch):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--batch", str(batch)] + common,
+                           capture_output=True, text=True, timeout=1500, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+    two, one = run(2, 8), run(1, 16)
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 16 and two["scaling"] == "weak"
+    assert two["ranks"]["backend"] == "nccl" and two["ranks"]["rccl_ranks"] == 2 and two["ranks"]["distinct_devices"] == 2
+    assert len({d.get("pci_bus_id") for d in two["ranks"]["devices"]}) == 2
+    assert two["scores"]["shape"] == [16, 10] and two["scores"]["sha256"] == one["scores"]["sha256"]

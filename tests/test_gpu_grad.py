@@ -69,7 +69,8 @@ def test_eps_vjp_is_the_same_with_kept_and_with_recomputed_pre_gate_activations(
     eps_a, saved_a = eg.forward_save(x, step)
     eps_b, saved_b = eg.forward_save(x, step, acts=False)
     assert saved_a[3] is not None and saved_a[3].shape == (3, B, 512, L) and saved_b[3] is None
-    assert torch.equal(eps_a, eps_b)
+    # (kept activations: the direct-form block with the pre-gate store; lean: the F(2,3) block -- the same eps to fp32 rounding)
+    assert rel_err(eps_a.cpu().numpy(), eps_b.cpu().numpy()) < 2e-6
     ga, gb = eg.backward(saved_a, v), eg.backward(saved_b, v)
     assert rel_err(ga.cpu().numpy(), gb.cpu().numpy()) < 1e-5
     # chain level: three links under a budget that holds (a) everything, (b) one full link + lean ones, (c) nothing
