@@ -88,11 +88,15 @@ int launch_pack_f32w(ap_ctx *ctx, hipStream_t st) {
   return 0;
 }
 
-template <bool NOH>
+template <bool NOH, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1w, const float *__restrict__ b1, const float *__restrict__ w2w,
     const float *__restrict__ b2, int L, int logd, int accumulate, int ntiles, int nblk) {
+  constexpr int ablate = ABL;
+  // (tools builds only instantiate ABL != 0; timing only, results wrong by construction) ablate: 1 gate math, 2 epilogue stores, 4 residual loads,
+  // 8 X loads of the chunk loop, 16 GEMM1 weight loads, 32 staging transform + LDS writes, 64 per-chunk barrier, 128 GEMM1 MFMAs,
+  // 256 GEMM2 MFMAs, 512 GEMM2 weight loads
   constexpr int C = WC_;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS_];
 
@@ -154,25 +158,24 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
   const int col0 = d >= 32 ? j : (((j >> logd) << (logd + 1)) + (j & (d - 1)));
   const int col1 = d >= 32 ? 32 + j : col0 + d;
 
-#pragma unroll 1
-  for (int tile = t_first; tile < t_end; tile += t_step) {
-    const int b = __builtin_amdgcn_readfirstlane(tile / ntiles);
-    const int p0 = __builtin_amdgcn_readfirstlane((tile % ntiles) * NP_);
-    const __amdgpu_buffer_rsrc_t hrs = uni_rsrc(hin + (size_t)b * C * L, clip_bytes);
-
-    // ---- staging geometry of this thread's pair
-    unsigned voff[4];
-    bool tok[4];
-    {
-      const int p = p0 + j;
-      const int tf = ((p >> logd) << (logd + 1)) + (p & (d - 1));
+  // ---- per-tile state, set one tile ahead (the next tile's first loads are requested before this tile's epilogue)
+  int b, p0;
+  __amdgpu_buffer_rsrc_t hrs;
+  unsigned voff[4];
+  bool tok[4];
+  auto set_tile = [&](int tile) {
+    b = __builtin_amdgcn_readfirstlane(tile / ntiles);
+    p0 = __builtin_amdgcn_readfirstlane((tile % ntiles) * NP_);
+    hrs = uni_rsrc(hin + (size_t)b * C * L, clip_bytes);
+    const int p = p0 + j;                                        // staging geometry of this thread's pair
+    const int tf = ((p >> logd) << (logd + 1)) + (p & (d - 1));
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int tp = tf + (k - 1) * d;
-        tok[k] = (tp >= 0) && (tp < L);
-        voff[k] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)(4 * sq) * (unsigned)L) * 4u;
-      }
+    for (int k = 0; k < 4; k++) {
+      const int tp = tf + (k - 1) * d;
+      tok[k] = (tp >= 0) && (tp < L);
+      voff[k] = ((unsigned)min(max(tp, 0), L - 1) + (unsigned)(4 * sq) * (unsigned)L) * 4u;
     }
+  };
     float xr[4][4];                                              // [channel of the quad][tap]
     f32x4 ptq;
     auto issue_x = [&](int ch) {
@@ -208,12 +211,21 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
       *reinterpret_cast<f32x4 *>(q + 3 * XCOMP_) = c3;
     };
 
-    // ---- prologue: first two k-groups of weights, first chunk of X
+    // ---- the first tile's first weights and first chunk of X (later tiles: requested at the end of the tile before)
     f32x4 a[4][4];                                               // [product][row tile]: a ring one k-group (four units, 64 MFMAs) deep
+    set_tile(t_first);
 #pragma unroll
     for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
     issue_x(0);
 
+#pragma unroll 1
+  for (int tile = t_first; tile < t_end; tile += t_step) {
+    if ((ablate & 2048) && tile != t_first) {                    // (A/B variant of the tools build: no cross-tile prefetch)
+      set_tile(tile);
+#pragma unroll
+      for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
+      issue_x(0);
+    }
     f32x16 acc[4][4];                                            // [product][row tile]; the dilated conv's bias rides on m2 (in both outputs)
 #pragma unroll
     for (int rt = 0; rt < 4; rt++) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 #pragma unroll 1
     for (int ch = 0; ch < NCH_; ch++) {
       const float *xb = xfrag + (ch & 1) * XBUF_;
-      issue_x(ch + 1 < NCH_ ? ch + 1 : ch);                      // (no branches in this loop: the last chunk re-requests itself, unused)
+      if (!(ablate & 8)) issue_x(ch + 1 < NCH_ ? ch + 1 : ch);   // (no branches in this loop: the last chunk re-requests itself, unused)
       f32x4 bq[2];
       bq[0] = *reinterpret_cast<const f32x4 *>(xb);
       __builtin_amdgcn_sched_barrier(0);
@@ -247,19 +259,29 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
         for (int comp = 0; comp < 4; comp++) {
           const int u = 4 * kg + comp;
           if (u + 1 < 16) bq[(u + 1) & 1] = *reinterpret_cast<const f32x4 *>(xb + ((u + 1) & 3) * XCOMP_ + ((u + 1) >> 2) * 8);
+          // the next chunk's FiLM add / padding / differences / LDS writes ride in the MFMA gaps of unit 12 (the X loads were
+          // requested twelve units = 12 k cycles ago)
+          if (u == 12 && !(ablate & 32)) store_x(lds + ((ch + 1) & 1) * XBUF_);
 #pragma unroll
           for (int e = 0; e < 4; e++)
 #pragma unroll
             for (int rt = 0; rt < 4; rt++)
-              acc[comp][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[comp][rt][e], bq[u & 1][e], acc[comp][rt], 0, 0, 0);
+              if (!(ablate & 128)) acc[comp][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[comp][rt][e], bq[u & 1][e], acc[comp][rt], 0, 0, 0);
+          if (u == 12 && !(ablate & 32)) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+          }
           __builtin_amdgcn_sched_barrier(0);
           // the same product's unit of the next k-group takes over this unit's registers
-          load_a1(a[comp], (unsigned)((16 * ch + u + 4) & (16 * NCH_ - 1)));   // (the last k-group wraps to the image's first units, unused)
-          if (u == 11) store_x(lds + ((ch + 1) & 1) * XBUF_);
+          if (!(ablate & 16)) load_a1(a[comp], (unsigned)((16 * ch + u + 4) & (16 * NCH_ - 1)));   // (the last k-group wraps to the image's first units, unused)
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      __syncthreads();
+      if (!(ablate & 64)) __syncthreads();
     }
 
     // sample of GEMM2 column (ct, j)
@@ -287,8 +309,8 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
             const float sa = (acc[0][2 * p + 1][r] + acc[1][2 * p + 1][r]) + acc[2][2 * p + 1][r];
             const float tb = (acc[1][2 * p][r] - acc[2][2 * p][r]) + acc[3][2 * p][r];
             const float sb = (acc[1][2 * p + 1][r] - acc[2][2 * p + 1][r]) + acc[3][2 * p + 1][r];
-            v0[e] = gate(ta, sa);
-            v1[e] = gate(tb, sb);
+            v0[e] = (ablate & 1) ? ta + sa : gate(ta, sa);
+            v1[e] = (ablate & 1) ? tb + sb : gate(tb, sb);
           }
           *reinterpret_cast<f32x4 *>(g0 + 32 * p + 8 * q) = v0;   // channels 64 wave + 32 p + 8 q + 4 hh + (0..3)
           *reinterpret_cast<f32x4 *>(g1 + 32 * p + 8 * q) = v1;
@@ -327,7 +349,11 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     // their waits do not include it -- and consumed after GEMM2: the epilogue never waits on memory.
     __builtin_amdgcn_sched_barrier(0);
     float hres[2][2][16];
-    if (!NOH) {
+    if (ablate & 4) {
+#pragma unroll
+      for (int i = 0; i < 64; i++) (&hres[0][0][0])[i] = 0.f;
+    }
+    if (!NOH && !(ablate & 4)) {
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -356,39 +382,55 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
             for (int rt = NOH ? 2 : 0; rt < 4; rt++)
 #pragma unroll
               for (int ct = 0; ct < 2; ct++)
-                acc2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[k & 1][rt][e], bq2[ct][e], acc2[rt][ct], 0, 0, 0);
+                if (!(ablate & 256)) acc2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[k & 1][rt][e], bq2[ct][e], acc2[rt][ct], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          load_a2(a2[k & 1], (unsigned)((kg + 2) & (C / 8 - 1)));
+          if (!(ablate & 512)) load_a2(a2[k & 1], (unsigned)((kg + 2) & (C / 8 - 1)));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
 
-    // ---- epilogue (WaveNet.py:97, :133)
-    {
+    // ---- the NEXT tile's first weights and first chunk of X are requested here, ahead of this tile's stores: vmcnt retires in
+    // order, so requested after them their wait would include the 64 float atomics (thousands of cycles each to retire with every
+    // CU issuing them); requested before, it includes at most the plain h' stores (the counter holds 63: the wait for these loads
+    // lets the youngest 63 operations -- the atomics -- stay outstanding)
+    const __amdgpu_buffer_rsrc_t ors = uni_rsrc((NOH ? skip : hout) + (size_t)b * C * L, clip_bytes);
+    const __amdgpu_buffer_rsrc_t srs = uni_rsrc(skip + (size_t)b * C * L, clip_bytes);     // S == C
+    if (!(ablate & 2048)) {
+      set_tile(tile + t_step < t_end ? tile + t_step : tile);    // (the last tile re-requests itself, unused)
+#pragma unroll
+      for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
+      issue_x(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue (WaveNet.py:97, :133): buffer stores / memory-side float atomics -- one VGPR offset per 32 x 32 tile, the row
+    // stride in SGPR offsets, columns past the clip's end dropped by the range check (no address arithmetic, no branches)
+    if (!(ablate & 2) || accumulate == 0x12345) {               // (ablated: kept behind a condition that is never true, so nothing upstream is dead code)
+      typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
       const float RS = 0.707106781186547524f;   // float(math.sqrt(0.5))
-      float *ho = hout + (size_t)b * C * L;
-      float *sk = skip + (size_t)b * C * L;     // S == C
 #pragma unroll
       for (int rt = NOH ? 2 : 0; rt < 4; rt++) {
 #pragma unroll
         for (int ct = 0; ct < 2; ct++) {
           const int t = tcol[ct];
-          const unsigned rbase = (unsigned)(64 * wave + 32 * (rt & 1) + 4 * hh) * (unsigned)L + (unsigned)t;
-          if (t < L) {
-            if (rt < 2) {
+          const unsigned eo = t < L ? ((unsigned)(64 * wave + 32 * (rt & 1) + 4 * hh) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
+          if (rt < 2) {
 #pragma unroll
-              for (int r = 0; r < 16; r++)
-                __builtin_nontemporal_store((hres[rt & 1][ct][r] + acc2[rt][ct][r]) * RS, &ho[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L]);
-            } else if (accumulate) {
+            for (int r = 0; r < 16; r++)
+              // nt (also the skip store below): once-written streams must not displace the h rows in the XCD's L2, which
+              // neighbouring tiles' taps and the residual read again
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (hres[rt & 1][ct][r] + acc2[rt][ct][r]) * RS), ors, eo,
+                                                    ((r & 3) + 8 * (r >> 2)) * L * 4, 2);
+          } else if (accumulate) {
 #pragma unroll
-              for (int r = 0; r < 16; r++)
-                unsafeAtomicAdd(&sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L], acc2[rt][ct][r]);
-            } else {
+            for (int r = 0; r < 16; r++)
+              (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc2[rt][ct][r], srs, (int)eo, ((r & 3) + 8 * (r >> 2)) * L * 4, 0);
+          } else {
+            const u32x16 av = __builtin_bit_cast(u32x16, acc2[rt][ct]);   // (the whole vector, then index: element-wise bit_cast of a vector element mis-folds to a splat)
 #pragma unroll
-              for (int r = 0; r < 16; r++)
-                __builtin_nontemporal_store(acc2[rt][ct][r], &sk[rbase + (unsigned)((r & 3) + 8 * (r >> 2)) * (unsigned)L]);
-            }
+            for (int r = 0; r < 16; r++)
+              __builtin_amdgcn_raw_buffer_store_b32(av[r], srs, eo, ((r & 3) + 8 * (r >> 2)) * L * 4, 2);
           }
         }
       }
@@ -399,6 +441,9 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 }
 
 static int g_ncu = 0;
+#ifdef AP_TOOLS
+static int g_ablate_f32w = 0;
+#endif
 
 bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L) {
   if (ctx->cfg.precision != AP_PREC_F32 || ctx->f32_form != 1 || ctx->C != WC_ || ctx->S != WC_ || !ctx->w1w) return false;
@@ -428,12 +473,45 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
   const unsigned grid = (unsigned)(nblk < g_ncu ? nblk : g_ncu);
-  if (hout)
-    resblock_f32w_kernel<false><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk);
-  else
-    resblock_f32w_kernel<true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk);
+#define AP_F32W(ABL)                                                                                                           \
+  do {                                                                                                                         \
+    if (hout) resblock_f32w_kernel<false, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk); \
+    else resblock_f32w_kernel<true, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk);      \
+  } while (0)
+#ifdef AP_TOOLS
+  switch (g_ablate_f32w) {                                       // each mask its own clean instantiation (tools/ablate_f32w.py)
+    case 0: AP_F32W(0); break;
+    case 1: AP_F32W(1); break;
+    case 2: AP_F32W(2); break;
+    case 4: AP_F32W(4); break;
+    case 6: AP_F32W(6); break;
+    case 8: AP_F32W(8); break;
+    case 16: AP_F32W(16); break;
+    case 32: AP_F32W(32); break;
+    case 40: AP_F32W(40); break;
+    case 64: AP_F32W(64); break;
+    case 512: AP_F32W(512); break;
+    case 528: AP_F32W(528); break;
+    case 128: AP_F32W(128); break;
+    case 256: AP_F32W(256); break;
+    case 384: AP_F32W(384); break;
+    case 639: AP_F32W(639); break;
+    case 2048: AP_F32W(2048); break;
+    default: set_error("ap_debug_ablate_f32w: mask %d is not instantiated", g_ablate_f32w); return -22;
+  }
+#else
+  AP_F32W(0);
+#endif
+#undef AP_F32W
   AP_HIP(hipGetLastError());
   return 0;
 }
 
 }  // namespace ap
+
+#ifdef AP_TOOLS
+extern "C" int ap_debug_ablate_f32w(int mask) {
+  ap::g_ablate_f32w = mask;
+  return 0;
+}
+#endif

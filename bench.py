@@ -51,15 +51,81 @@ def _cpu_model() -> str:
     return platform.processor() or platform.machine()
 
 
+_CPU_CHILD = r"""
+import sys, time, torch
+sys.path.insert(0, %r)
+from audiopure_amd import synth
+from oracle import diffwave_oracle as O
+torch.set_num_threads(int(sys.argv[1]))
+cfg = dict(synth.FULL_WAVENET_CONFIG)
+w = O.fold_state_dict(synth.wavenet_state_dict(cfg, 0))
+dh = O.diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+m5 = synth.m5_state_dict(10)
+x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234))
+z = [torch.from_numpy(synth.noise(0, 2, 16000, seed=1234))]
+print("READY", flush=True)
+t = time.time(); O.purify_and_classify(w, cfg, dh, m5, x0, 1, z); print("CALL", time.time() - t, flush=True)
+t = time.time(); O.purify_and_classify(w, cfg, dh, m5, x0, 1, z); print("CALL", time.time() - t, flush=True)
+"""
+
+
+def _all_cores_attempt(threads: int, bound_s: float = 20.0):
+    """SURVEY 8(d) asks for torch.set_num_threads(os.cpu_count()).  On the GPU hosts seen so far (2 x 64-core EPYC, 256 hardware
+    threads) one 2-clip evaluation at that setting takes ~90 s (oneDNN's fork-join over 256 threads on a batch of two), three
+    times the whole default bench -- so the attempt runs in a child process, is cut off after `bound_s` of compute, and the
+    object reports what happened; `value` is then the thread count that performs (`cores` says which)."""
+    import subprocess
+    t0 = time.time()
+    calls, ready = [], None
+    try:
+        p = subprocess.Popen([sys.executable, "-c", _CPU_CHILD % ROOT, str(threads)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    except OSError as e:
+        return {"threads": threads, "status": f"not started ({e})"}
+    import selectors
+    sel = selectors.DefaultSelector()
+    sel.register(p.stdout, selectors.EVENT_READ)
+    deadline = None
+    while True:
+        now = time.time()
+        if ready is None and now - t0 > 120:                      # imports + weight synthesis never finished
+            break
+        if deadline is not None and now > deadline:
+            break
+        if not sel.select(timeout=0.5):
+            if p.poll() is not None:
+                break
+            continue
+        line = p.stdout.readline()
+        if not line:
+            break
+        if line.startswith("READY"):
+            ready = time.time()
+            deadline = ready + bound_s
+        elif line.startswith("CALL"):
+            calls.append(float(line.split()[1]))
+            if len(calls) == 2:
+                break
+    if p.poll() is None:
+        p.kill()
+    p.wait()
+    if len(calls) == 2:
+        return {"threads": threads, "status": "completed", "s_per_call": round(calls[1], 3), "value": round(2.0 / calls[1], 4)}
+    return {"threads": threads, "status": f"cut off after {bound_s:.0f} s of compute with {len(calls)} of 2 calls finished",
+            "s_first_call": round(calls[0], 3) if calls else None,
+            "note": "one 2-clip, 1-step evaluation at this thread count measured ~90 s on this host class (profiles/r5_cpu_baseline_threads.txt)"}
+
+
 def cpu_baseline(budget_s: float = 25.0):
-    """The oracle ("port") timed as SURVEY.md section 8(d) fixes it: BASELINE configs[0] -- 2 clips, DiffWave DDPM n = 1 + M5, fp32 --
-    with torch.set_num_threads(os.cpu_count()), CPU model and core count in the object.  The same 2 clips at the metric's n = 5
-    (on at most 32 threads: oneDNN scales poorly past a few dozen on a 2-clip batch) ride along as `n5_value`.  Bounded: a
-    one-step warm-up, up to three n = 1 calls, one or two n = 5 calls -- 10-25 s of CPU work."""
+    """The oracle ("port") on BASELINE configs[0] as SURVEY.md section 8(d) fixes it -- 2 clips, DiffWave DDPM n = 1 + M5, fp32,
+    CPU model and thread count in the object.  `all_cores`: the same call at torch.set_num_threads(os.cpu_count()), attempted in a
+    bounded child process (see _all_cores_attempt); when it completes and beats the 32-thread figure it IS `value`.  The same 2
+    clips at the metric's n = 5 ride along as `n5_value`.  Bounded: 10-30 s of CPU work here, at most 20 s more in the child."""
     import torch
     from audiopure_amd import synth
     from oracle import diffwave_oracle as O
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 32)
+    allc = _all_cores_attempt(ncpu) if ncpu > cores else None
     torch.set_num_threads(cores)
     cfg = dict(synth.FULL_WAVENET_CONFIG)
     w = O.fold_state_dict(synth.wavenet_state_dict(cfg, 0))
@@ -76,8 +142,6 @@ def cpu_baseline(budget_s: float = 25.0):
         dt = time.time() - t1
         best1 = dt if best1 is None else min(best1, dt)
         runs1 += 1
-    cores5 = min(cores, 32)
-    torch.set_num_threads(cores5)
     best5, runs5 = None, 0
     while runs5 < 2 and (runs5 == 0 or (time.time() - t0) + best5 < budget_s):
         t1 = time.time()
@@ -85,13 +149,15 @@ def cpu_baseline(budget_s: float = 25.0):
         dt = time.time() - t1
         best5 = dt if best5 is None else min(best5, dt)
         runs5 += 1
-    torch.set_num_threads(cores)
-    return {"value": round(2.0 / best1, 4), "unit": "utterances/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "n_reverse_steps": 1, "n5_value": round(2.0 / best5, 4), "n5_cores": cores5,
+    value, used = 2.0 / best1, cores
+    if allc and allc.get("status") == "completed" and allc["value"] > value:
+        value, used = allc["value"], allc["threads"]
+    return {"value": round(value, 4), "unit": "utterances/s", "cores": used, "kind": "port", "cpu_model": _cpu_model(),
+            "host_threads": ncpu, "n_reverse_steps": 1, "all_cores": allc, "n5_value": round(2.0 / best5, 4), "n5_cores": cores,
             "sample": f"CPU oracle (PyTorch-CPU fp32 restatement of the reference path) on BASELINE configs[0]: 2 clips x 1 reverse "
-                      f"step + M5 on all {cores} host threads, best of {runs1} calls ({best1:.2f} s per call) after a one-step "
-                      f"warm-up; n5_value: the same 2 clips x 5 reverse steps (the metric's step count) on {cores5} threads, best "
-                      f"of {runs5} ({best5:.2f} s per call)"}
+                      f"step + M5 on {cores} threads, best of {runs1} calls ({best1:.2f} s per call) after a one-step warm-up; "
+                      f"`all_cores`: the same call at os.cpu_count() = {ncpu} threads in a bounded child process; n5_value: the same "
+                      f"2 clips x 5 reverse steps (the metric's step count), best of {runs5} ({best5:.2f} s per call)"}
 
 
 PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32; dilated conv in F(2,3) minimal-filtering form)",

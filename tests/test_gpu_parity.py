@@ -109,6 +109,48 @@ def test_resblock_matches_oracle(dev, C_, L, layer):
     assert rel_err(sk2.cpu().numpy(), s_ref.numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("L,layer", [(16000, 0), (16000, 1), (16000, 4), (16000, 5), (16000, 6), (16000, 7), (16000, 11), (4133, 8),
+                                     (4133, 11), (1000, 11), (130, 3), (130, 9), (77, 0), (5, 1), (1, 0), (2, 0), (3, 1), (63, 5),
+                                     (64, 5), (65, 5), (16001, 9), (333, 6)])
+def test_minimal_filtering_resblock_matches_oracle(dev, L, layer):
+    """The shipped-shape fp32 block (C = S = 256) in its F(2,3) form (ap_resblock_f32w.hip) vs the oracle's direct-form
+    Residual_block.forward (WaveNet.py:75-97) at the direct kernel's tolerance: every dilation class (d < 32, = 32, > 32), d >= L,
+    ragged and tiny clips, both skip modes -- and the direct form of the same context (ap_ctx_set_f32_form) beside it."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    lib = eng.lib
+    assert lib.ap_ctx_get_f32_form(eng.ctx) == 1
+    B = 3
+    h = torch.from_numpy(synth.uniform(f"h/256/{L}", (B, 256, L), 1, -1.5, 1.5))
+    skip0 = torch.from_numpy(synth.uniform(f"s/256/{L}", (B, 256, L), 1, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    with torch.no_grad():
+        p = f"residual_layer.residual_blocks.{layer}"
+        part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        h_ref, s_ref = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb)
+    hd, pt = h.to(dev), part_t.to(dev).contiguous()
+    outs = {}
+    try:
+        for form in (1, 0):
+            N.check(lib.ap_ctx_set_f32_form(eng.ctx, form))
+            sk = skip0.to(dev).clone()
+            hout = torch.full_like(hd, 3.0)
+            N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
+            sk2 = torch.full_like(sk, 7.0)
+            N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk2), 0, B, L, N.stream()))
+            assert rel_err(hout.cpu().numpy(), h_ref.numpy()) < 5e-6, form
+            assert rel_err(sk.cpu().numpy(), (skip0 + s_ref).numpy()) < 5e-6, form
+            assert rel_err(sk2.cpu().numpy(), s_ref.numpy()) < 5e-6, form
+            outs[form] = hout.cpu().numpy()
+    finally:
+        N.check(lib.ap_ctx_set_f32_form(eng.ctx, 1))
+    assert rel_err(outs[1], outs[0]) < 3e-6
+
+
 def test_embed_matches_oracle(mini, dev):
     from audiopure_amd import _native as N
     O = _oracle()

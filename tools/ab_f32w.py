@@ -1,0 +1,51 @@
+"""Same-process A/B of variants of the F(2,3) fp32 block (tools build; variant masks >= 1024 keep the results right).
+   python tools/ab_f32w.py [B] [mask ...]"""
+import sys
+
+import _toolslib  # noqa: F401
+import ctypes as C
+
+import torch
+
+from audiopure_amd import synth, _native as N
+from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    masks = [int(a) for a in sys.argv[2:]] or [0, 2048]
+    dev = torch.device("cuda:0")
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net = WaveNet_Speech_Commands(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(cfg, 3).items()})
+    net = net.to(dev)
+    eng = net.engine()
+    lib = eng.lib
+    lib.ap_debug_ablate_f32w.argtypes = [C.c_int]
+    L = 16000
+    hd = torch.rand(B, 256, L, device=dev) * 3 - 1.5
+    hout = torch.empty_like(hd)
+    sk = torch.zeros_like(hd)
+    pt = torch.rand(256, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def t(layer, mask, n=6):
+        lib.ap_debug_ablate_f32w(mask)
+        for _ in range(2):
+            N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
+        e0.record()
+        for _ in range(n):
+            N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        lib.ap_debug_ablate_f32w(0)
+        return e0.elapsed_time(e1) / n
+
+    for rep in range(2):
+        for layer in (0, 5, 11):
+            row = [t(layer, m) for m in masks]
+            print(f"layer {layer:2d}  " + "  ".join(f"mask {m}: {ms:7.3f} ms" for m, ms in zip(masks, row)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
