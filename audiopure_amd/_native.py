@@ -59,6 +59,8 @@ SIGNATURES = {
     "ap_init_conv": (_i, [_vp, _fp, _fp, _i, _i, _vp]),
     "ap_resblock_fwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_resblock_fwd_save": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    "ap_resblock_bwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
+    "ap_resblock_bwd_available": (_i, [_vp, _i, _i]),
     "ap_resblock_fwd_gate": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "ap_skip_gemm": (_i, [_vp, _i, _i, _vp, _fp, _i, _i, _i, _vp]),
     "ap_ctx_set_skip_group": (_i, [_vp, _i]),

@@ -105,6 +105,8 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->slab_h = nullptr;
   c->slab_w = nullptr;
   c->w1w = c->w2w = nullptr;
+  c->slab_b = nullptr;
+  c->w2t = c->w1b = nullptr;
   c->f32_form = 1;
   c->w1p_h = c->w2p_h = nullptr;
   c->w1p_s = c->w2p_s = nullptr;
@@ -142,6 +144,7 @@ extern "C" int ap_ctx_destroy(ap_ctx *ctx) {
   if (ctx->slab_s) (void)hipFree(ctx->slab_s);
   if (ctx->slab_h) (void)hipFree(ctx->slab_h);
   if (ctx->slab_w) (void)hipFree(ctx->slab_w);
+  if (ctx->slab_b) (void)hipFree(ctx->slab_b);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
@@ -280,6 +283,12 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
   AP_HIP(hipMemcpyAsync(ctx->emb_freq, embed_freq_dev, sizeof(float) * (Ein / 2), hipMemcpyDeviceToDevice, st));
   int rc = launch_fold_and_pack(ctx, blob_dev, st);
   if (rc) return rc;
+  if (ctx->slab_b) {                                            // (re-loaded weights: the backward images are rebuilt at the next backward call)
+    AP_HIP(hipStreamSynchronize(st));
+    (void)hipFree(ctx->slab_b);
+    ctx->slab_b = nullptr;
+    ctx->w2t = ctx->w1b = nullptr;
+  }
   if (c.precision == AP_PREC_BF16) {
     const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
     if (!ctx->slab_bf) {

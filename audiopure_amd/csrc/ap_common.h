@@ -85,6 +85,8 @@ struct ap_ctx {
   void *slab_h;
   float *w1w, *w2w;         // AP_PREC_F32, C = S = 256: F(2,3)-transformed GEMM1 image and GEMM2 image of ap_resblock_f32w.hip, own allocation
   void *slab_w;
+  float *w2t, *w1b;         // backward images of ap_resblock_bwd.hip (allocated at the first backward call), own allocation
+  void *slab_b;
   int f32_form;             // AP_PREC_F32: 1 = minimal-filtering (Winograd) block where built (default), 0 = direct-form block
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
@@ -185,7 +187,7 @@ int launch_resblock_bf16w(ap_ctx *ctx, int layer, const float *hin, const float 
 int launch_pack_f32w(ap_ctx *ctx, hipStream_t st);
 bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L);       // AP_PREC_F32 in minimal-filtering form, and this shape is built
 int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                         int accumulate, int B, int L, hipStream_t st);   // hout null: the net's last layer (no res_conv, no h'); returns 1 if the shape is not served
+                         int accumulate, int B, int L, hipStream_t st, float *aout = nullptr);   // hout null: the net's last layer (no res_conv, no h'); returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
 int launch_pack_splith(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,

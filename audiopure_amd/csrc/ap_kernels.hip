@@ -543,7 +543,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
   }
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
-  if (!aout && !g_force_direct && resblock_f32w_serves(ctx, B, L)) {     // F(2,3) form of the dilated conv (ap_resblock_f32w.hip)
+  if (!g_force_direct && resblock_f32w_serves(ctx, B, L)) {     // F(2,3) form of the dilated conv (ap_resblock_f32w.hip)
     hipEvent_t w0 = nullptr, w1e = nullptr;
     if (ctx->profile) {
       if (ctx->ev_used + 2 > ctx->ev.size())
@@ -559,7 +559,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
       ctx->ev_used += 2;
       AP_HIP(hipEventRecord(w0, st));
     }
-    const int rcw = launch_resblock_f32w(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+    const int rcw = launch_resblock_f32w(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, aout);
     if (w1e) AP_HIP(hipEventRecord(w1e, st));
     return rcw;
   }

@@ -88,11 +88,13 @@ int launch_pack_f32w(ap_ctx *ctx, hipStream_t st) {
   return 0;
 }
 
-template <bool NOH, int ABL = 0>
+// SAVE (the differentiable path's forward pass, ap_resblock_fwd_save): the pre-gate activations y = DilConv(u) + b are also written
+// to aout [B][2C][L] (rows 0..C-1 the tanh half, C..2C-1 the sigmoid half: what ap_resblock_bwd reads).
+template <bool NOH, int ABL = 0, bool SAVE = false>
 __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1w, const float *__restrict__ b1, const float *__restrict__ w2w,
-    const float *__restrict__ b2, int L, int logd, int accumulate, int ntiles, int nblk) {
+    const float *__restrict__ b2, int L, int logd, int accumulate, int ntiles, int nblk, float *__restrict__ aout) {
   constexpr int ablate = ABL;
   // (tools builds only instantiate ABL != 0; timing only, results wrong by construction) ablate: 1 gate math, 2 epilogue stores, 4 residual loads,
   // 8 X loads of the chunk loop, 16 GEMM1 weight loads, 32 staging transform + LDS writes, 64 per-chunk barrier, 128 GEMM1 MFMAs,
@@ -289,6 +291,16 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     int tcol[2];
     tcol[0] = tfirst + j;
     tcol[1] = tfirst + (d >= 32 ? d : 32) + j;
+    // SAVE: this lane's pair's two samples as byte offsets into the clip's pre-gate rows (past the clip: dropped by the range check)
+    __amdgpu_buffer_rsrc_t ars = hrs;
+    unsigned sv0 = 0, sv1 = 0;
+    if constexpr (SAVE) {
+      ars = uni_rsrc(aout + (size_t)b * 2 * C * L, 2u * clip_bytes);
+      const int pj = p0 + j;
+      const int s0 = ((pj >> logd) << (logd + 1)) + (pj & (d - 1));
+      sv0 = s0 < L ? (unsigned)s0 * 4u : 0x80000000u;
+      sv1 = s0 + d < L ? (unsigned)(s0 + d) * 4u : 0x80000000u;
+    }
     // ---- output transform, gate (WaveNet.py:90) -> g image [column][channel]
     {
       float *g0 = lds + GOFF_ + col0 * GS_ + 64 * wave + 4 * hh;
@@ -311,6 +323,14 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
             const float sb = (acc[1][2 * p + 1][r] - acc[2][2 * p + 1][r]) + acc[3][2 * p + 1][r];
             v0[e] = (ablate & 1) ? ta + sa : gate(ta, sa);
             v1[e] = (ablate & 1) ? tb + sb : gate(tb, sb);
+            if constexpr (SAVE) {                                // channel 64 wave + 32 p + rowoff(r, hh), samples of this lane's pair
+              const unsigned so = ((unsigned)(64 * wave + 32 * p + 4 * hh) * (unsigned)L) * 4u;
+              const int ro = ((r & 3) + 8 * (r >> 2)) * L * 4;
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ta), ars, so + sv0, ro, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sa), ars, so + sv0 + (unsigned)C * (unsigned)L * 4u, ro, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tb), ars, so + sv1, ro, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sb), ars, so + sv1 + (unsigned)C * (unsigned)L * 4u, ro, 0);
+            }
           }
           *reinterpret_cast<f32x4 *>(g0 + 32 * p + 8 * q) = v0;   // channels 64 wave + 32 p + 8 q + 4 hh + (0..3)
           *reinterpret_cast<f32x4 *>(g1 + 32 * p + 8 * q) = v1;
@@ -447,13 +467,13 @@ static int g_ablate_f32w = 0;
 
 bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L) {
   if (ctx->cfg.precision != AP_PREC_F32 || ctx->f32_form != 1 || ctx->C != WC_ || ctx->S != WC_ || !ctx->w1w) return false;
-  if ((size_t)WC_ * (size_t)L * 4 >= ((size_t)1 << 31)) return false;
+  if ((size_t)2 * WC_ * (size_t)L * 4 >= ((size_t)1 << 31)) return false;   // (the pre-gate rows of the SAVE form: 2C rows per clip)
   return (long long)B * ((L + 2 * NP_ - 1) / (2 * NP_) + 1) < (1ll << 31);
 }
 
 // returns 1 if the shape is not served (caller: the direct-form kernel)
 int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                         int B, int L, hipStream_t st) {
+                         int B, int L, hipStream_t st, float *aout) {
   if (!resblock_f32w_serves(ctx, B, L)) return 1;
   if (g_ncu == 0) {
     int dev = 0, n = 0;
@@ -473,10 +493,16 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
   const unsigned grid = (unsigned)(nblk < g_ncu ? nblk : g_ncu);
+  if (aout) {
+    if (!hout) { set_error("resblock (save): needs an h' buffer"); return -22; }
+    resblock_f32w_kernel<false, 0, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
+    AP_HIP(hipGetLastError());
+    return 0;
+  }
 #define AP_F32W(ABL)                                                                                                           \
   do {                                                                                                                         \
-    if (hout) resblock_f32w_kernel<false, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk); \
-    else resblock_f32w_kernel<true, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk);      \
+    if (hout) resblock_f32w_kernel<false, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
+    else resblock_f32w_kernel<true, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);      \
   } while (0)
 #ifdef AP_TOOLS
   switch (g_ablate_f32w) {                                       // each mask its own clean instantiation (tools/ablate_f32w.py)

@@ -11,8 +11,11 @@ with the states x_t check-pointed in the forward pass.  A link's 37 layer inputs
 chain fits a memory budget (``SAVE_BUDGET_BYTES``; 288 GB of HBM hold a PGD batch comfortably) and recomputed otherwise
 (the adjoint's memory/compute trade).
 
-``J_eps^T v`` runs on the HIP library: the residual blocks' forward is the fused kernel (``ap_resblock_fwd``), the
-three GEMM-shaped backward terms of a block -- the recomputed dilated conv, ``W2^T [dh'; dskip]`` and the transposed
+``J_eps^T v`` runs on the HIP library.  Shipped shape (res = skip = 256 channels), fp32: the forward keeps the pre-gate
+activations (``ap_resblock_fwd_save``) and a block's backward is ``ap_resblock_bwd`` -- two fused launches (the gate's
+derivative behind ``W2^T [dh'; dskip]``, then the transposed dilated conv in F(2,3) form with the residual path in its
+epilogue): the forward block's flops, no elementwise glue.  Every other shape / arithmetic mode: the residual blocks'
+forward is the fused kernel (``ap_resblock_fwd``), the three GEMM-shaped backward terms of a block -- the recomputed dilated conv, ``W2^T [dh'; dskip]`` and the transposed
 dilated conv -- are ``ap_conv2d_fwd`` calls in ``AP_CONV_1D`` mode (MFMA conv-as-GEMM, weights streamed as
 fragments), with ``ap_gate_bwd`` / ``ap_relu_outer_bwd`` / ``ap_init_conv_bwd`` between them.  Gradients with respect
 to the network's parameters are not formed (the attack differentiates with respect to the audio only; parameters
@@ -157,6 +160,18 @@ class EpsGrad:
         self._conv(lib, dr, self.wf1_t, None, None, dskip, B, S_, L, S_, 1, 0, 1)
         N.check(lib.ap_copy_channels(N.ptr(dskip), N.ptr(z), B, S_, L, S_, 0, C_ + S_, C_, st), "ap_copy_channels")
         dh = torch.zeros((B, C_, L), device=dev)                  # the last block's h' output is not used (WaveNet.py:133)
+        if pre is not None and self.net._precision == N.AP_PREC_F32 and lib.ap_resblock_bwd_available(eng.ctx, B, L):
+            # the shipped shape in fp32: two fused launches per layer (ap_resblock_bwd.hip) -- the gate's derivative as the epilogue of
+            # W2^T [dh'; dskip], then the transposed dilated conv in its F(2,3) form with the residual path added in its epilogue
+            dy = torch.empty((B, 2 * C_, L), device=dev)
+            dh2 = torch.empty_like(dh)
+            for n in range(NL - 1, -1, -1):
+                N.check(lib.ap_resblock_bwd(eng.ctx, n, N.ptr(dh), N.ptr(dskip), N.ptr(pre[n]), N.ptr(dy), N.ptr(dh2), B, L, st),
+                        "ap_resblock_bwd")
+                dh, dh2 = dh2, dh
+            dx = torch.empty((B, 1, L), device=dev)
+            N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")
+            return dx
         t1 = torch.empty_like(dh)
         dg = torch.empty_like(dh)
         u = torch.empty_like(dh) if pre is None else None

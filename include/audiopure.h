@@ -209,6 +209,17 @@ int ap_resblock_fwd_save(ap_ctx *ctx, int layer, const float *h_in, const float 
  * with an affine update of the clip:  eps = W_f2 ReLU(W_f1 (skip*sqrt(1/N)) + b_f1) + b_f2;
  *   out = ca * x + cb * eps + cs * z.
  * eps_out and/or out may be NULL.  z: see header comment (NULL + cs != 0 -> Philox draw `draw`). */
+/* ap_resblock_bwd: input gradient of one Residual_block.forward (WaveNet.py:75-97; the reference's autograd does this for
+ * robustness_eval/white_box_attack.py:392,437-439), two fused launches (ap_resblock_bwd.hip):
+ *   dy = gate'(pre_gate) . ([W_res sqrt(1/2); W_skip]^T [dh_out; dskip])       -> dy_scratch [B][2C][L]
+ *   dh_in = sqrt(1/2) dh_out + DilConv^T(dy)                                    (F(2,3) form of the transposed dilated conv)
+ * dh_out = d loss / d h' [B][C][L] (zeros for the net's last layer, whose h' is unused), dskip = d loss / d skip_n [B][S][L] (the
+ * same tensor for every layer: skip is their sum), pre_gate: what ap_resblock_fwd_save kept for this layer.  Parameters are
+ * frozen (no weight gradients).  AP_PREC_F32, res = skip = 256 channels; ap_resblock_bwd_available says whether a shape is served. */
+int ap_resblock_bwd(ap_ctx *ctx, int layer, const float *dh_out, const float *dskip, const float *pre_gate, float *dy_scratch,
+                    float *dh_in, int B, int L, void *stream);
+int ap_resblock_bwd_available(ap_ctx *ctx, int B, int L);
+
 int ap_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out,
                     float ca, float cb, float cs, const float *z, uint64_t seed, uint32_t draw,
                     uint64_t utt_offset, int B, int L, void *stream);

@@ -414,3 +414,48 @@ def test_convnet_backward_covers_cat_slices_and_pools(dev):
     (g,) = torch.autograd.grad(out, xd, v.to(dev))
     d = np.abs(g.cpu().numpy() - g_ref.numpy()) / float(np.abs(g_ref.numpy()).max())
     assert d.max() < 2e-2 and np.median(d) < 1e-5, (d.max(), np.median(d))
+
+
+@pytest.mark.parametrize("L,layer", [(1100, 0), (2048, 5), (1000, 11), (16000, 6), (130, 3), (77, 9), (5, 1), (129, 6), (4133, 7), (16000, 1),
+                                     (1, 0), (64, 4), (4100, 10)])
+def test_fused_block_backward_matches_autograd_through_the_oracle(dev, L, layer):
+    """ap_resblock_fwd_save + ap_resblock_bwd (one block's backward as two fused launches) at the shipped
+    width: the kept pre-gate activations equal the oracle's y = DilConv(u) + b, the save-forward equals the plain forward bit
+    for bit, and dh_in equals torch autograd through the oracle's Residual_block.forward (WaveNet.py:75-97) for random
+    cotangents on h' and skip_n -- every dilation class, d >= L, ragged and tiny clips."""
+    import torch.nn.functional as F
+    from oracle import diffwave_oracle as O
+    from audiopure_amd import _native as N
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    lib = eng.lib
+    B, C_, d = 2, 256, 2 ** (layer % 12)
+    assert lib.ap_resblock_bwd_available(eng.ctx, B, L) == 1
+    h = torch.from_numpy(synth.uniform(f"gh/{L}", (B, C_, L), 1, -1.5, 1.5))
+    gh = torch.from_numpy(synth.uniform(f"gg/{L}", (B, C_, L), 2, -1.0, 1.0))
+    gs = torch.from_numpy(synth.uniform(f"gs/{L}", (B, C_, L), 3, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    p = f"residual_layer.residual_blocks.{layer}"
+    hr = h.clone().requires_grad_(True)
+    h_ref, s_ref = O.residual_block(w, layer, d, hr, emb)
+    (g_ref,) = torch.autograd.grad([h_ref, s_ref], hr, [gh, gs])
+    with torch.no_grad():
+        part_t = F.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        y_ref = F.conv1d(h + part_t.view(1, -1, 1), w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"],
+                         dilation=d, padding=d)
+    hd, pt = h.to(dev), part_t.to(dev).contiguous()
+    hout, hout2 = torch.empty_like(hd), torch.empty_like(hd)
+    sk, sk2 = torch.zeros_like(hd), torch.zeros_like(hd)
+    pre = torch.full((B, 2 * C_, L), 9.0, device=dev)
+    N.check(lib.ap_resblock_fwd_save(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), N.ptr(pre), 0, B, L, N.stream()))
+    N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout2), N.ptr(sk2), 0, B, L, N.stream()))
+    assert torch.equal(hout, hout2) and torch.equal(sk, sk2)
+    assert rel_err(hout.cpu().numpy(), h_ref.detach().numpy()) < 5e-6
+    assert rel_err(pre.cpu().numpy(), y_ref.numpy()) < 5e-6
+    dy = torch.empty_like(pre)
+    dh_in = torch.full_like(hd, 5.0)
+    ghd, gsd = gh.to(dev), gs.to(dev)                            # (held: a temporary's block would be reused by the next .to())
+    N.check(lib.ap_resblock_bwd(eng.ctx, layer, N.ptr(ghd), N.ptr(gsd), N.ptr(pre), N.ptr(dy), N.ptr(dh_in), B, L, N.stream()))
+    assert rel_err(dh_in.cpu().numpy(), g_ref.numpy()) < 1e-5
