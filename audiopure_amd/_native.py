@@ -16,7 +16,6 @@ LIB_PATH = os.environ.get("AUDIOPURE_HIP_LIB") or os.path.join(_HERE, "lib", "li
 AP_PREC_F32 = 0
 AP_PREC_BF16 = 1
 AP_PREC_F32_SPLIT = 2
-AP_PREC_F32_SPLIT_F16 = 3
 
 
 class NativeError(RuntimeError):

@@ -64,13 +64,12 @@ static int check_cfg(const ap_config &c) {
     set_error("config: invalid layer/embedding/schedule sizes");
     return -22;
   }
-  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16 && c.precision != AP_PREC_F32_SPLIT &&
-      c.precision != AP_PREC_F32_SPLIT_F16) {
-    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16, AP_PREC_F32_SPLIT, AP_PREC_F32_SPLIT_F16)", c.precision);
+  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16 && c.precision != AP_PREC_F32_SPLIT) {
+    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16, AP_PREC_F32_SPLIT)", c.precision);
     return -22;
   }
   if (c.precision != AP_PREC_F32 && c.res_channels != 256) {
-    set_error("config: AP_PREC_BF16 / AP_PREC_F32_SPLIT / AP_PREC_F32_SPLIT_F16 are built for res_channels = 256 only (got %d)",
+    set_error("config: AP_PREC_BF16 / AP_PREC_F32_SPLIT are built for res_channels = 256 only (got %d)",
               c.res_channels);
     return -22;
   }
@@ -102,13 +101,11 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->slab_bf = nullptr;
   c->w1p_bf = c->w2p_bf = c->wf1p_bf = c->w1q_bf = nullptr;
   c->slab_s = nullptr;
-  c->slab_h = nullptr;
   c->slab_w = nullptr;
   c->w1w = c->w2w = nullptr;
   c->slab_b = nullptr;
   c->w2t = c->w1b = nullptr;
   c->f32_form = 1;
-  c->w1p_h = c->w2p_h = nullptr;
   c->w1p_s = c->w2p_s = nullptr;
   c->profile = false;
   c->ev_used = 0;
@@ -142,7 +139,6 @@ extern "C" int ap_ctx_destroy(ap_ctx *ctx) {
   if (ctx->slab) (void)hipFree(ctx->slab);
   if (ctx->slab_bf) (void)hipFree(ctx->slab_bf);
   if (ctx->slab_s) (void)hipFree(ctx->slab_s);
-  if (ctx->slab_h) (void)hipFree(ctx->slab_h);
   if (ctx->slab_w) (void)hipFree(ctx->slab_w);
   if (ctx->slab_b) (void)hipFree(ctx->slab_b);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
@@ -325,16 +321,6 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
       ctx->w2p_s = (char *)ctx->slab_s + n1 * 3 * 2;
     }
     rc = launch_pack_split(ctx, st);
-    if (rc) return rc;
-  }
-  if (c.precision == AP_PREC_F32_SPLIT_F16) {
-    const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
-    if (!ctx->slab_h) {
-      AP_HIP(hipMalloc(&ctx->slab_h, (n1 + n2) * 2 * 2));
-      ctx->w1p_h = ctx->slab_h;
-      ctx->w2p_h = (char *)ctx->slab_h + n1 * 2 * 2;
-    }
-    rc = launch_pack_splith(ctx, st);
     if (rc) return rc;
   }
   AP_HIP(hipStreamSynchronize(st));

@@ -81,8 +81,6 @@ struct ap_ctx {
   void *slab_bf;
   void *w1p_s, *w2p_s;      // 3-way bf16-split images (AP_PREC_F32_SPLIT), own allocation
   void *slab_s;
-  void *w1p_h, *w2p_h;      // 2-way fp16-split images (AP_PREC_F32_SPLIT_F16), own allocation
-  void *slab_h;
   float *w1w, *w2w;         // AP_PREC_F32, C = S = 256: F(2,3)-transformed GEMM1 image and GEMM2 image of ap_resblock_f32w.hip, own allocation
   void *slab_w;
   float *w2t, *w1b;         // backward images of ap_resblock_bwd.hip (allocated at the first backward call), own allocation
@@ -189,9 +187,6 @@ bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L);       // AP_PREC_F32
 int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st, float *aout = nullptr);   // hout null: the net's last layer (no res_conv, no h'); returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
-int launch_pack_splith(ap_ctx *ctx, hipStream_t st);
-int launch_resblock_splith(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                           int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);
 int launch_m5(ap_m5 *m, const float *x, float *logprobs, int B, int L, hipStream_t st);

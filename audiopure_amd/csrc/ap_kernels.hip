@@ -535,9 +535,7 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
     }
     int rc = ctx->cfg.precision == AP_PREC_BF16
                  ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout)
-             : ctx->cfg.precision == AP_PREC_F32_SPLIT
-                 ? launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st)
-                 : launch_resblock_splith(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
+                 : launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
     if (e1) AP_HIP(hipEventRecord(e1, st));
     return rc;
   }

@@ -198,13 +198,12 @@ class WaveNet_Speech_Commands(nn.Module):
     def set_precision(self, mode: str):
         """"f32": exact fp32 MFMA (default, the reference's arithmetic); at res = skip = 256 channels the dilated conv runs in its
         F(2,3) minimal-filtering form (include/audiopure.h: ap_ctx_set_f32_form), "f32d" keeps the direct form.  "f32s": fp32 operands split exactly into three
-        bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results, ~2x faster.
-        "f32h": fp32 operands carried as two fp16 parts (22 significant bits), three partial products on the fp16 MFMA,
-        fp32 accumulate -- fp32-class results, ~2x faster again.
+        bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results (held to the fp32
+        tolerances and, on adversarial operands, to twice the direct fp32 kernel's error against fp64), ~1.3x the F(2,3) form's rate.
         "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  All but "f32" need
         res_channels = 256."""
         prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "f32d": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
-                "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "f32h": N.AP_PREC_F32_SPLIT_F16}[mode]
+                "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT}[mode]
         self._f32_form = 0 if mode == "f32d" else 1
         if prec != self._precision:
             self._precision = prec

@@ -90,8 +90,6 @@ class EpsGrad:
     def _conv(self, lib, x, packed, bias, res, out, B, Cin, L, Cout, kw, pad, dil, flags=0):
         if self.net._precision == N.AP_PREC_F32_SPLIT:           # follow the network's arithmetic mode
             flags |= 0x100                                       # AP_CONV_SPLIT
-        elif self.net._precision == N.AP_PREC_F32_SPLIT_F16:
-            flags |= 0x400                                       # AP_CONV_SPLIT_F16
         fl = flags | _F1D | ((dil << 16) if dil > 1 else 0)
         N.use_conv_workspace(x.device)                           # short clips meet the split-K condition: this device's buffer
         N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(packed), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, 1, L, Cout, 1, kw, 1,

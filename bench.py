@@ -13,7 +13,7 @@ the global utterance index, one RCCL all_gather of the [B,10] log-probabilities 
 `python bench.py --gpus N` with N > 1 and no RANK in the environment starts the N ranks itself as CHILD processes
 (`python -m torch.distributed.run ... bench.py --gpus N ...`, before anything touches a GPU) and relays rank 0's line;
 `--dry-run` does the same on CPU with the gloo backend (launcher / sharding / gather plumbing only, no kernels).
-At N = 1 the same run then times the bf16 mode of the path (`other_modes`; `--experimental-modes` adds the frozen f32s / f32h),
+At N = 1 the same run then times the other arithmetic modes of the path (`other_modes`: bf16, the fp32-class split mode f32s, the direct-form fp32 block),
 BASELINE configs[3] / configs[4] as their own workloads and the callers' batch shapes (`other_configs`), each with its own roofline object.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = fused residual block, timed with HIP
@@ -162,19 +162,17 @@ def cpu_baseline(budget_s: float = 25.0):
 
 PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32; dilated conv in F(2,3) minimal-filtering form)",
              "f32d": "fp32 (v_mfma_f32_32x32x2_f32; direct-form dilated conv: the round 1-4 kernel)", "bf16": "bf16",
-             "f32s": "fp32 via exact 3-way bf16 operand split, 6 partial products on the bf16 MFMA, fp32 accumulate",
-             "f32h": "fp32 operands as two fp16 parts (22 significant bits, exact power-of-two scaling), 3 partial products "
-                     "on the fp16 MFMA, fp32 accumulate"}
+             "f32s": "fp32-class: exact 3-way bf16 operand split, 6 partial products on the bf16 MFMA, fp32 accumulate (direct-form "
+                     "dilated conv; held to the fp32 tolerances and to 2 x the fp32 kernel's error on adversarial operands)"}
 
 
 PMC_FILES = {"f32": ["r5_f32w_pmc_traffic.json"], "f32d": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3_f32s_pmc_traffic.json", "r2_f32s_pmc_traffic.json"],
-             "f32h": ["r3_f32h_pmc_traffic.json", "r2_f32h_pmc_traffic.json"],
              "bf16": ["r4_bf16_pmc_traffic.json"]}
 
 
 class PowerSampler:
     """Board power and shader clock of GPU 0 while a leg runs (`rocm-smi` polled from a side thread every 0.5 s: a host process,
-    nothing on the GPU's queues) -> the `power` object of that leg: the bf16 / f32s / f32h block kernels sit at the package's
+    nothing on the GPU's queues) -> the `power` object of that leg: the bf16 / f32s block kernels sit at the package's
     power cap and the firmware lowers the clock under them, and the line should say so itself.  None when
     rocm-smi is missing or prints nothing usable."""
 
@@ -445,13 +443,13 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="clips per GPU per step")
     ap.add_argument("--reverse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-modes", action="store_true", help="time only --precision (skip the f32s / f32h / bf16 legs)")
-    ap.add_argument("--precision", choices=["f32", "f32s", "f32h", "bf16"], default="f32",
+    ap.add_argument("--no-other-modes", action="store_true", help="time only --precision (skip the bf16 / f32s / f32d legs)")
+    ap.add_argument("--precision", choices=["f32", "f32s", "bf16"], default="f32",
                     help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
     ap.add_argument("--experimental-modes", action="store_true",
-                    help="also time the frozen split-operand modes f32s / f32h under other_modes (about 50 s more)")
+                    help="(kept for old command lines; f32s is timed by default since round 5)")
     ap.add_argument("--no-caller-shapes", action="store_true", help="skip the callers' batch shapes leg (B = 1, 2, 10, 50, ...)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + gather protocol; no kernels")
     ap.add_argument("--chunk", type=int, default=0,
@@ -607,14 +605,6 @@ def main():
                     "note": "algorithmic fp32 flops; each is 6 v_mfma_f32_32x32x16_bf16 partial products (exact 3-way "
                             "bf16 operand split, fp32 accumulate), so peak = 2500 TFLOP/s dense bf16 / 6",
                     "executed_bf16_TFLOPs": round(6 * achieved, 1)}
-        elif precision == "f32h":
-            peak = 2500.0 / 3.0                       # 3 fp16 MFMAs (same rate as bf16) per fp32 MFMA-equivalent
-            roof = {"bound": "mfma", "kernel": "resblock_f32h_kernel<256>", "achieved": round(achieved, 2),
-                    "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                    "traffic": traffic,
-                    "note": "algorithmic fp32 flops; each is 3 v_mfma_f32_32x32x16_f16 partial products (operands as two "
-                            "fp16 parts, fp32 accumulate), so peak = 2500 TFLOP/s dense fp16 / 3",
-                    "executed_f16_TFLOPs": round(3 * achieved, 1)}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
             sp = getattr(run_mode, "split", {})
@@ -656,8 +646,7 @@ def main():
     # not the headline): same inputs, same chain, same timing brackets
     others = {}
     if world == 1 and not args.no_other_modes:
-        # (f32s / f32h: experimental modes, frozen since round 3 -- timed only on request)
-        for prec in (("f32s", "f32h") if args.experimental_modes else ()) + ("bf16", "f32d", "f32"):
+        for prec in ("bf16", "f32s", "f32d", "f32"):
             if prec == args.precision:
                 continue
             if prec == "f32d" or (prec == "f32" and args.precision != "f32"):   # (one step: the direct-form A/B of the same run)
@@ -759,7 +748,7 @@ def main():
             "metric": f"purified 1s@16kHz utterances/sec at {n} reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision in ("f32s", "f32h") else args.precision, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32s" else args.precision, "data": "synthetic",
             "config": {"workload": f"DiffWave {args.sampler.upper()} purify n={n} + M5 classify, batch={B}/GPU, 1 s @ 16 kHz "
                                    f"clips, {PREC_NAME[args.precision]} (BASELINE.json configs[{3 if args.precision == 'bf16' else 1}]); "
                                    "shipped config C=S=256, 36 layers",

@@ -49,13 +49,14 @@ enum {
   AP_PREC_BF16 = 1,  /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM.  Built for the shipped
                         configuration only: res_channels == skip_channels == 256 (any dilation of a power-of-two cycle,
                         any clip length); other shapes return -EINVAL at the first launch (ap_last_error says which) */
-  AP_PREC_F32_SPLIT = 2, /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
+  AP_PREC_F32_SPLIT = 2  /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
                             each product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-class results (dropped
-                            terms < 2^-23 of a product) at 6/16 of the fp32 matrix instruction's time; C = 256 */
-  AP_PREC_F32_SPLIT_F16 = 3  /* fp32 operands carried as two fp16 parts (22 significant bits, exact power-of-two
-                                scaling for the exponent range), three partial products on v_mfma_f32_32x32x16_f16,
-                                fp32 accumulate: 3/16 of the fp32 instruction's time; dot-product noise between
-                                plain fp32's and AP_PREC_F32_SPLIT's; C = 256 */
+                            terms < 2^-23 of a product) at 6/16 of the fp32 matrix instruction's time; C = 256.  Held to the
+                            fp32 kernels' tolerances, and on adversarial operands (cancellation, a 2^40 dynamic range)
+                            to <= 2 x the direct fp32 kernel's error against fp64
+                            (tests/test_gpu_parity.py::test_fp32_class_modes_bound_their_error_on_adversarial_operands) */
+  /* (value 3, AP_PREC_F32_SPLIT_F16 -- two fp16 parts per operand -- was removed in round 5: fp16's exponent range loses
+     channels a 2^20 dynamic range apart outright, profiles/r5_fp32_class_adversarial_error.txt) */
 };
 
 /* configs/config.json "wavenet_config" + "diffusion_config" (reference: configs/config.json:2-17) */
@@ -308,8 +309,8 @@ int ap_melspec_db(const float *x, float *out, int n_mels, int mode, int B, int L
  *   `relu` is a flag word: bit 0 = fused ReLU, bit 8 (AP_CONV_SPLIT) = run eligible layers (Cin/g % 16 == 0,
  *   Cout/g >= 64) on the bf16 MFMA with exactly 3-way-split fp32 operands (AP_PREC_F32_SPLIT's arithmetic); bit 9
  *   (AP_CONV_1D) = padding and dilation apply to W only (nn.Conv1d over [B][C][1][L]); bit 10 (AP_CONV_SPLIT_F16) = the
- *   same layers with operands as two fp16 parts, three partial products on the fp16 MFMA (AP_PREC_F32_SPLIT_F16's
- *   arithmetic: |w|, |x| < 3750); bits 16-31 = dilation (0 = 1).
+ *   same layers with operands as two fp16 parts, three partial products on the fp16 MFMA (valid for |w|, |x| < 3750 and a
+ *   narrow dynamic range only -- the normalised activations of the UNet; not an fp32-class mode); bits 16-31 = dilation (0 = 1).
  *   nn.Linear is the kh = kw = H = W = 1 case. */
 size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, int groups);   /* floats ap_conv2d_pack writes */
 int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw, int groups,

@@ -189,7 +189,7 @@ def test_mini_ddpm_chain_matches_reference_golden(golden, mini, dh, dev):
     assert rel_err(x.cpu().numpy(), golden["mini/ddpm_n3"]) < TOL_CHAIN
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32h", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "f32s", "bf16"])
 def test_full_size_batch_is_the_small_batch_on_shared_clips(golden, dev, dh, mode):
     """BASELINE configs[1] at its full size (512 clips, shipped config, DDPM n = 5): utterances are independent and the
     Philox noise is keyed on the global utterance index, so clips 0-1 and 510-511 of the 512-clip run must equal, bit
@@ -681,7 +681,7 @@ def test_split_resblock_matches_oracle_at_the_fp32_tolerance(dev, L, layer):
     hd = h.to(dev)
     pt = part_t.to(dev).contiguous()
     outs = {}
-    for mode in ("f32", "f32s", "f32h"):
+    for mode in ("f32", "f32s"):
         net.set_precision(mode)
         eng = net.engine()
         sk = skip0.to(dev).clone()
@@ -693,43 +693,62 @@ def test_split_resblock_matches_oracle_at_the_fp32_tolerance(dev, L, layer):
         N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk2), 0, B, L, N.stream()))
         assert rel_err(sk2.cpu().numpy(), s_ref.numpy()) < 5e-6, mode
         outs[mode] = (hout.cpu().numpy(), sk2.cpu().numpy())
-    for mode in ("f32s", "f32h"):
+    for mode in ("f32s",):
         assert rel_err(outs[mode][0], outs["f32"][0]) < 2e-6, mode
         assert rel_err(outs[mode][1], outs["f32"][1]) < 2e-6, mode
 
 
-@pytest.mark.parametrize("amp", [1e-3, 1e-2, 1.0, 40.0, 600.0])
-def test_f32h_block_over_five_decades_of_activation_scale(dev, amp):
-    """The fp16 two-part split has a bounded exponent range (exact 2^4 scaling, residual parts go subnormal below
-    2^-7, clamp at 3750): the block with its input scaled over five decades, f32h and the exact fp32 kernel each
-    against the (fp32, CPU) oracle.  Measured: 1.1e-6 / 1.0e-6 / 6e-7 / 3e-6 / 3e-5 of max for f32h at 1e-3 .. 600
-    against 1.5e-6 / 1.3e-6 / 1e-6 / 4e-6 / 4e-5 for the fp32 kernel -- the same rounding-noise class at every scale
-    (for huge inputs the gate saturates and its few transition points amplify ANY fp32-class difference, hence the
-    bound relative to the fp32 kernel's own distance from the oracle)."""
+def _adversarial_cases(B, C, L):
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(B, C, L, generator=g)
+    out = {"unit": base}
+    x = base.clone()                                                # cancellation: channel 2k+1 = -(channel 2k)(1 + 2^-12 noise), scale 64
+    x[:, 1::2] = -x[:, 0::2] * (1 + 2.0 ** -12 * torch.randn(B, C // 2, L, generator=g))
+    out["cancel"] = 64.0 * x
+    for name, span in (("range10", 10), ("range20", 20)):             # dynamic range: channel c scaled by 2^e(c), e = -span .. span
+        e = torch.linspace(-span, span, C).view(1, C, 1).round()
+        out[name] = base * torch.pow(2.0, e)
+    return out
+
+
+@pytest.mark.parametrize("layer", [2, 7])
+def test_fp32_class_modes_bound_their_error_on_adversarial_operands(dev, layer):
+    """VERDICT r4 item 7 (promote or delete the split-operand kernels): AP_PREC_F32_SPLIT is promoted to a documented fp32-class
+    mode on this evidence, the fp16 two-part mode was deleted on it (its error under a 2^20 dynamic range is 2e-1 of max:
+    profiles/r5_fp32_class_adversarial_error.txt).  Per-dot-product error of the block against an fp64 evaluation of
+    Residual_block.forward (WaveNet.py:75-97) on adversarial operands -- channel pairs that cancel to 2^-12, a 2^20 and a 2^40
+    dynamic range across the contraction, plain unit-scale data: the split mode and the F(2,3) form stay within twice the
+    direct-form fp32 kernel's own error (+ 3 x on the 2^40 case for F(2,3), whose input differences round once more;
+    measured <= 1.2 x and <= 1.9 x)."""
     from audiopure_amd import _native as N
     O = _oracle()
-    C_, L, B, layer = 256, 2048, 2, 7
+    C_, L, B = 256, 2048, 2
     net, sd = _net(synth.mini_wavenet_config(C_, 12, 12), dev, seed=3)
     w = O.fold_state_dict(sd)
-    h = torch.from_numpy(synth.uniform(f"amp/{L}", (B, C_, L), 1, -1.5, 1.5)) * amp
-    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
-    with torch.no_grad():
-        p = f"residual_layer.residual_blocks.{layer}"
-        part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
-        h_ref, s_ref = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb)
-    hd, pt = h.to(dev), part_t.to(dev).contiguous()
-    err = {}
-    for mode in ("f32", "f32h"):
-        net.set_precision(mode)
-        eng = net.engine()
-        ho, sk = torch.empty_like(hd), torch.zeros_like(hd)
-        N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(ho), N.ptr(sk), 0, B, L, N.stream()))
-        err[mode] = max(rel_err(ho.cpu().numpy(), h_ref.numpy()), rel_err(sk.cpu().numpy(), s_ref.numpy()))
-    print(f"amp {amp}: vs oracle  f32 {err['f32']:.2e}  f32h {err['f32h']:.2e}")
-    assert err["f32h"] < 3.0 * err["f32"] + 2e-6, (amp, err)
+    w64 = {k: v.double() for k, v in w.items()}
+    p = f"residual_layer.residual_blocks.{layer}"
+    part = w[p + ".fc_t.bias"].clone()                               # emb = 0: part_t is fc_t's bias
+    for name, h in _adversarial_cases(B, C_, L).items():
+        with torch.no_grad():
+            h64, s64 = O.residual_block(w64, layer, 2 ** layer, h.double(), torch.zeros(B, 512, dtype=torch.float64))
+        err = {}
+        for mode in ("f32d", "f32", "f32s"):
+            net.set_precision(mode)
+            eng = net.engine()
+            hd, ptd = h.to(dev), part.to(dev).contiguous()
+            ho, sk = torch.empty_like(hd), torch.zeros_like(hd)
+            N.check(eng.lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ho), N.ptr(sk), 0, B, L, N.stream()))
+            err[mode] = (float((ho.cpu().double() - h64).abs().max() / h64.abs().max()),
+                         float((sk.cpu().double() - s64).abs().max() / s64.abs().max()))
+        print(f"layer {layer} {name}: " + "  ".join(f"{m} {a:.2e}/{b:.2e}" for m, (a, b) in err.items()))
+        for k in (0, 1):
+            floor = 2e-8
+            assert err["f32s"][k] <= 2.0 * err["f32d"][k] + floor, (name, k, err)
+            assert err["f32"][k] <= (3.0 if name == "range20" else 2.0) * err["f32d"][k] + floor, (name, k, err)
+    net.set_precision("f32")
 
 
-@pytest.mark.parametrize("mode", ["f32s", "f32h"])
+@pytest.mark.parametrize("mode", ["f32s"])
 def test_split_full_chain_matches_reference_golden_at_the_fp32_tolerance(golden, dev, dh, mode):
     """Whole shipped-config DDPM n=5 + one-shot denoise in the split modes vs the reference's fp32 golden vectors, at the
     tolerances the exact-fp32 tests use (TOL_CHAIN / TOL_EVAL)."""
@@ -784,7 +803,7 @@ def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
         sk0 = torch.from_numpy(synth.uniform(f"sws/{L}/{layer}", (B, C_, L), 1, -1.0, 1.0)).to(dev)
         pt = torch.from_numpy(synth.uniform(f"swp/{layer}", (C_,), 1, -0.5, 0.5)).to(dev)
         outs = {}
-        for mode in ("f32", "f32s", "f32h", "bf16"):
+        for mode in ("f32", "f32s", "bf16"):
             net.set_precision(mode)
             eng = net.engine()
             sk, ho = sk0.clone(), torch.empty_like(h)
@@ -793,7 +812,6 @@ def test_all_three_block_kernels_agree_over_a_shape_sweep(dev):
             outs[mode] = (ho.cpu().numpy(), sk.cpu().numpy())
         for k in (0, 1):
             assert rel_err(outs["f32s"][k], outs["f32"][k]) < 2e-6, (B, L, layer, k)
-            assert rel_err(outs["f32h"][k], outs["f32"][k]) < 2e-6, (B, L, layer, k)
             assert rel_err(outs["bf16"][k], outs["f32"][k]) < 3e-2, (B, L, layer, k)
 
 

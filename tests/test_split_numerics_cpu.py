@@ -51,43 +51,3 @@ def test_six_partial_products_match_an_fp32_gemm():
     assert e6 < 4 * e_plain and e6 < 1e-6              # fp32-class: the longer accumulation chain, not the dropped terms,
     assert abs(e6 - e9) < 0.2 * e9                     # is what separates it from the plain fp32 GEMM
     assert e1 > 1000 * e6                              # (plain bf16 operands are 3-4 orders of magnitude away)
-
-
-# ---- AP_PREC_F32_SPLIT_F16 (csrc/ap_resblock_f32h.hip): two fp16 parts, three partial products --------------------------
-def split2h(a, scale):
-    """fp16 RNE parts of a * scale (the kernel's exact power-of-two operand scaling)."""
-    v = a * scale
-    h = v.half().float()
-    return h, (v - h).half().float()
-
-
-def test_two_fp16_parts_carry_22_bits():
-    g = torch.Generator().manual_seed(2)
-    x = torch.cat([torch.randn(1 << 16, generator=g) * s for s in (0.05, 1.0, 30.0)])
-    h, lo = split2h(x, 16.0)
-    err = ((h.double() + lo.double()) / 16.0 - x.double()).abs()
-    # 2^-22 relative while the residual part sits in fp16's normal range; below that the error is absolute: half an
-    # fp16 subnormal step (2^-25) over the scale
-    assert (err <= torch.clamp(x.abs().double() * 2.0 ** -22, min=2.0 ** -29)).all()
-    assert torch.equal(((x * 16.0) - h).half().float(), lo)     # and the residual itself is exact in fp32
-
-
-def test_three_fp16_partial_products_match_an_fp32_gemm():
-    """Same GEMM as above: noise between the plain fp32 GEMM's and the 6-term bf16 split's (half as many
-    accumulations), for O(1) activations and for activations two decades smaller."""
-    g = torch.Generator().manual_seed(1)
-    K, M, N = 768, 128, 256
-    w = torch.randn(M, K, generator=g) * 0.05
-    x0 = torch.randn(K, N, generator=g) * 1.2
-    for amp, bound in ((1.0, 3.0), (1e-2, 12.0)):
-        x = x0 * amp
-        ref = w.double() @ x.double()
-        ws, xs = split2h(w, 16.0), split2h(x, 16.0)
-        acc, plain = torch.zeros(M, N), torch.zeros(M, N)
-        for k0 in range(0, K, 16):
-            for i, j in ((0, 0), (0, 1), (1, 0)):
-                acc += ws[i][:, k0:k0 + 16] @ xs[j][k0:k0 + 16, :]
-            plain += w[:, k0:k0 + 16] @ x[k0:k0 + 16, :]
-        rms = lambda v: float((v.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
-        e3, e_plain = rms(acc / 256.0), rms(plain)
-        assert e3 < bound * e_plain and e3 < 2e-6, (amp, e3, e_plain)
