@@ -923,6 +923,20 @@ static int g_conv_no_frag = 0;     // ap_debug_conv_path(1): timing A/B against 
 static long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
 static int g_conv_wide_1x1 = 0;               // ap_debug_conv_path(2): pointwise layers on 128 x 128 tiles again (A/B)
 static int g_conv_force = 0;                  // ap_debug_conv_path(4..7): every streamed-weight layer on 128x128 / 128x64 / 64x64 / 64x128 tiles; 8: off
+static int g_conv_w3 = 1;                     // ap_debug_conv_w3(on, min_pairs): the F(2,3) kernel for the layers it serves / the direct kernels
+static long long g_conv_w3_min_pairs = 0;
+extern "C" int ap_debug_conv_w3(int on, int min_pairs) {
+  g_conv_w3 = on;
+  g_conv_w3_min_pairs = min_pairs;
+  return 0;
+}
+static long long g_conv_splitk_t2 = 384;      // ap_debug_conv_splitk: split-K is taken below this many half-tiles (2 x 128 x 128 tiles)
+static int g_conv_splitk_cap = 768;           // ... and slices are doubled while tiles x slices stays below this
+extern "C" int ap_debug_conv_splitk(int t2, int cap) {
+  g_conv_splitk_t2 = t2;
+  g_conv_splitk_cap = cap;
+  return 0;
+}
 extern "C" int ap_debug_conv_path(int no_frag) {
   if (no_frag >= 16) g_conv_frag_min_tiles = no_frag;   // >= 16: set the tile-count threshold of the streamed-weight kernel
   else if (no_frag >= 4 && no_frag <= 8) g_conv_force = no_frag == 8 ? 0 : no_frag;
@@ -934,7 +948,24 @@ extern "C" int ap_debug_conv_path(int no_frag) {
 static constexpr int g_conv_no_frag = 0;
 static constexpr long long g_conv_frag_min_tiles = 512;   // below two 128 x 128 tiles per CU the 128 x 64 variant wins (swept)
 static constexpr int g_conv_wide_1x1 = 0;
+static constexpr long long g_conv_splitk_t2 = 384;
+static constexpr int g_conv_splitk_cap = 768;
+static constexpr int g_conv_w3 = 1;
+static constexpr long long g_conv_w3_min_pairs = 0;
 #endif
+
+// ap_conv_w3.hip: 3 x 3 / stride 1 / pad 1 / ungrouped layers in F(2,3) form along W; their transformed-weight image is the LAST image
+namespace ap {
+bool conv_w3_serves(int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups);
+bool conv_w3_worth(int B, int H, int W, int Cout);
+size_t conv_w3_elems(int Cout, int Cin);
+int launch_conv_pack_w3(const float *w, const float *scale, float *out, int Cout, int Cin, hipStream_t st);
+int launch_conv_w3(const float *x, const float *wimg, const float *bias, const float *res, float *out, int B, int Cin, int H, int W,
+                   int Cout, int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, hipStream_t st);
+}
+static bool conv_has_w3(int Cout, int Cin_g, int kh, int kw, int groups) {
+  return conv_w3_serves(Cin_g, 4, 4, Cout, kh, kw, 1, 1, groups);      // the weight-side conditions (kernel 3 x 3, ungrouped, Cin % 32, Cout % 128)
+}
 
 // layers the streamed-weight kernel serves carry a second image behind the first
 static bool conv_has_frag(int Cout, int Cin_g, int groups) { return Cin_g % 16 == 0 && Cout / groups >= 64; }
@@ -959,7 +990,12 @@ extern "C" size_t ap_conv2d_packed_elems(int Cout, int Cin_g, int kh, int kw, in
   if (conv_has_frag(Cout, Cin_g, groups))
     n = ((n + 3) & ~(size_t)3) + conv_frag_elems(Cout, Cin_g, kh, kw, groups) + conv_split_floats(Cout, Cin_g, kh, kw, groups) +
         conv_splith_floats(Cout, Cin_g, kh, kw, groups);
+  if (conv_has_w3(Cout, Cin_g, kh, kw, groups)) n = ((n + 3) & ~(size_t)3) + conv_w3_elems(Cout, Cin_g);
   return n;
+}
+// offset (floats) of the F(2,3) image inside a packed weight buffer
+static size_t conv_w3_offset(int Cout, int Cin_g, int kh, int kw, int groups) {
+  return ((ap_conv2d_packed_elems(Cout, Cin_g, kh, kw, groups) - conv_w3_elems(Cout, Cin_g)));
 }
 
 extern "C" int ap_conv2d_pack(const float *w, const float *scale, float *wT, int Cout, int Cin_g, int kh, int kw,
@@ -977,6 +1013,10 @@ extern "C" int ap_conv2d_pack(const float *w, const float *scale, float *wT, int
     conv_pack_splith_kernel<<<(unsigned)((nf + 255) / 256), 256, 0, (hipStream_t)stream>>>(
         w, scale, reinterpret_cast<_Float16 *>(wT + n4 + nf + conv_split_floats(Cout, Cin_g, kh, kw, groups)), Cout, Cin_g,
         kh * kw, groups);
+  }
+  if (conv_has_w3(Cout, Cin_g, kh, kw, groups)) {
+    int rc = launch_conv_pack_w3(w, scale, wT + conv_w3_offset(Cout, Cin_g, kh, kw, groups), Cout, Cin_g, (hipStream_t)stream);
+    if (rc) return rc;
   }
   AP_HIP(hipGetLastError());
   return 0;
@@ -1053,7 +1093,7 @@ extern "C" int ap_conv_profile_launch(int i, double *ms, double *flop, int *shap
 }
 
 extern "C" int ap_conv_profile_read(double *ms_by_class, double *flop_by_class, int64_t *launches_by_class, int n_classes) {
-  if (!ms_by_class || !flop_by_class || !launches_by_class || n_classes < 6) { set_error("ap_conv_profile_read: bad argument"); return -22; }
+  if (!ms_by_class || !flop_by_class || !launches_by_class || n_classes < 7) { set_error("ap_conv_profile_read: bad argument"); return -22; }
   for (int c = 0; c < n_classes; c++) { ms_by_class[c] = 0; flop_by_class[c] = 0; launches_by_class[c] = 0; }
   for (size_t i = 0; i < g_cprof.flop.size(); i++) {
     AP_HIP(hipEventSynchronize(g_cprof.ev[2 * i + 1]));
@@ -1151,6 +1191,13 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     set_error("ap_conv2d_fwd_slice: this layer is not served by the streamed-weight fp32 kernel (Cin/g %% 16, Cout/g >= 64, no split-operand flag)");
     return -22;
   }
+  if (g_conv_w3 && !split && !splith && !one_d && dil == 1 && conv_w3_serves(Cin, H, W, Cout, kh, kw, stride, pad, groups) &&
+      (size_t)B * x_cstride * H * W * sizeof(float) < ((size_t)1 << 31) && (size_t)B * a.o_cstride * H * W * sizeof(float) < ((size_t)1 << 31) &&
+      (g_conv_w3 == 2 || conv_w3_worth(B, H, W, Cout)) && (long long)B * H * (W / 2) >= g_conv_w3_min_pairs) {   // (g_conv_w3 == 2, tools: every served layer)
+    *cls = 6;
+    return launch_conv_w3(x, wT + conv_w3_offset(Cout, Cin, kh, kw, groups), bias, res, out, B, Cin, H, W, Cout, relu, x_cstride, x_coff,
+                          a.o_cstride, a.o_coff, (hipStream_t)stream);
+  }
   if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
     const size_t n1 = (size_t)Cout * (Cin / groups) * kh * kw;
     const float *afrag = wT + ((n1 + 3) & ~(size_t)3);
@@ -1210,7 +1257,7 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
       if (buf && p1) conv2d_f32_big2_kernel<128, 128, true, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else if (buf) conv2d_f32_big2_kernel<128, 128, true><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, (unsigned)xbytes, (unsigned)abytes);
       else conv2d_f32_big2_kernel<128, 128, false><<<grid, 256, 0, (hipStream_t)stream>>>(a, afrag, 0u, 0u);
-    } else if (const ConvWs cws = (buf && groups == 1 && !split && !splith && tiles128 * 2 < 384 && kh * kw * (Cin / 16) >= 32)
+    } else if (const ConvWs cws = (buf && groups == 1 && !split && !splith && tiles128 * 2 < g_conv_splitk_t2 && kh * kw * (Cin / 16) >= 32)
                                       ? conv_ws_here() : ConvWs{};
                cws.p && 2 * (size_t)B * Cout * a.Ho * a.Wo * sizeof(float) <= cws.bytes) {
       // too few output tiles for 256 CUs and a long K (the 4 x 4 and 8 x 8 maps of the UNet: K = 2 304 .. 4 608): split-K over
@@ -1219,7 +1266,7 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
       const bool small = t128x64 < 192;
       const long long tiles = small ? t64 : t128x64;
       int S = 2;
-      while (S < 8 && tiles * S < 768 && kh * kw * (Cin / 16) / (2 * S) >= 16 &&
+      while (S < 8 && tiles * S < g_conv_splitk_cap && kh * kw * (Cin / 16) / (2 * S) >= 16 &&
              (size_t)(2 * S) * B * Cout * a.Ho * a.Wo * sizeof(float) <= cws.bytes) S *= 2;
       a.splits = S;
       a.part = cws.p;

@@ -134,7 +134,8 @@ int ap_profile_read_split(ap_ctx *ctx, double *ms_by_kind, int64_t *launches_by_
  * that stand in for nn.Conv2d / nn.Conv1d / nn.Linear of improved_diffusion/unet.py:462-491 and models/resnext.py:67-142):
  * while enabled every ap_conv2d_fwd launch is bracketed by HIP events on its stream.  ap_conv_profile_read sums kernel
  * time, algorithmic flops (2 N M K) and launches per kernel class -- 0 conv2d_f32_big2<128,128>, 1 big2<64,128>,
- * 2 big2<128,64>, 3 split-operand kernels, 4 conv2d_f32_big, 5 generic -- into caller arrays of n_classes >= 6, and resets.
+ * 2 big2<128,64>, 3 split-operand kernels, 4 conv2d_f32_big, 5 generic, 6 conv2d_w3 (3 x 3 layers in F(2,3) form along W: its flops are
+ * the DIRECT form's 2 N M K, of which it executes two thirds) -- into caller arrays of n_classes >= 7, and resets.
  * A measurement aid with process-global state: enable it from ONE host thread, for launches of ONE device on ONE stream at a time
  * (bench.py's use); it is off by default and the compute entry points never depend on it. */
 /* Caller-owned device buffer for the split-K partial sums of low-resolution conv layers (K sliced over workgroups when a layer

@@ -214,3 +214,41 @@ def test_conv_output_written_as_a_channel_slice_is_bit_identical_and_touches_not
     wide = torch.zeros(2, 96, 8, 8, device=dev)
     assert lib.ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), None, None, N.ptr(wide), 2, 24, 8, 8, 64, 3, 3, 1, 1, 1, 0, 24, 0, 96, 0, N.stream()) == -22
     assert float(wide.abs().max()) == 0.0
+
+
+def test_conv3x3_minimal_filtering_kernel_matches_conv2d(dev):
+    """ap_conv2d_fwd on the layers its F(2,3)-along-W kernel serves (3 x 3, stride 1, pad 1, ungrouped, Cin % 32 == 0, Cout % 128
+    == 0, even W: the UNet's ResBlock convolutions, improved_diffusion/unet.py:150-197) vs torch's conv2d: both workgroup shapes
+    (Cout % 256 == 0 and not), maps from 2 x 2 to 32 x 32, ragged pair-column tiles, bias / residual / ReLU, a channel-sliced input
+    and a channel-sliced output."""
+    import torch.nn.functional as F
+    from audiopure_amd import _native as N
+    lib = N.lib()
+    # (the launcher takes this kernel from 512 tiles on: B sized so that every case has them -- small maps need many images)
+    cases = [(2050, 32, 8, 8, 128, True, True, 1), (4100, 64, 4, 4, 256, True, False, 0), (260, 128, 32, 32, 128, False, True, 1), (258, 32, 16, 16, 256, True, True, 0),
+             (33000, 32, 2, 2, 128, True, False, 0), (1101, 96, 6, 10, 384, True, True, 1), (2731, 32, 3, 4, 512, False, False, 1)]
+    for (B, Cin, H, W, Cout, has_b, has_r, relu) in cases:
+        x = torch.from_numpy(synth.uniform(f"w3x{Cin}{H}{W}", (B, Cin + 5, H, W), 1)).to(dev)       # the conv reads channels [3, 3 + Cin)
+        w = torch.from_numpy(synth.uniform(f"w3w{Cin}{Cout}", (Cout, Cin, 3, 3), 1)).to(dev) * 0.1
+        b = torch.from_numpy(synth.uniform(f"w3b{Cout}", (Cout,), 1)).to(dev) if has_b else None
+        r = torch.from_numpy(synth.uniform(f"w3r{Cout}{H}", (B, Cout, H, W), 1)).to(dev) if has_r else None
+        ref = F.conv2d(x[:, 3:3 + Cin].double(), w.double(), None if b is None else b.double(), padding=1)
+        if r is not None:
+            ref = ref + r.double()
+        if relu:
+            ref = F.relu(ref)
+        wT = torch.empty(lib.ap_conv2d_packed_elems(Cout, Cin, 3, 3, 1), device=dev)
+        N.check(lib.ap_conv2d_pack(N.ptr(w), None, N.ptr(wT), Cout, Cin, 3, 3, 1, N.stream()))
+        out = torch.full((B, Cout, H, W), 9.0, device=dev)
+        N.check(lib.ap_conv_profile_enable(1))
+        N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(r), N.ptr(out), B, Cin, H, W, Cout, 3, 3, 1, 1, 1, relu, Cin + 5, 3, N.stream()))
+        import ctypes as C
+        ms, fl, n = (C.c_double * 8)(), (C.c_double * 8)(), (C.c_int64 * 8)()
+        N.check(lib.ap_conv_profile_read(ms, fl, n, 8))
+        N.check(lib.ap_conv_profile_enable(0))
+        assert n[6] == 1, (list(n), "the F(2,3) kernel did not take this layer")
+        assert rel_err(out.cpu().numpy(), ref.float().cpu().numpy()) < 2e-6, (B, Cin, H, W, Cout)
+        wide = torch.full((B, Cout + 7, H, W), 4.0, device=dev)                                       # out = channels [2, 2 + Cout) of a wider tensor
+        N.check(lib.ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(r), N.ptr(wide), B, Cin, H, W, Cout, 3, 3, 1, 1, 1, relu, Cin + 5, 3,
+                                        Cout + 7, 2, N.stream()))
+        assert torch.equal(wide[:, 2:2 + Cout], out) and bool((wide[:, :2] == 4.0).all()) and bool((wide[:, 2 + Cout:] == 4.0).all())

@@ -27,7 +27,7 @@ h = torch.randn(B, 256, L, device=dev); ho = torch.empty_like(h); sk = torch.zer
 zero = os.environ.get("AP_ZERO") == "1"
 if zero:
     h.zero_(); pt.zero_()
-for prec in ("bf16", "f32s", "f32h", "f32"):
+for prec in ("bf16", "f32s", "f32d", "f32"):
     net = WaveNet_Speech_Commands(**dict(synth.FULL_WAVENET_CONFIG)).to(dev).set_precision(prec)
     eng = net.engine(); lib = eng.lib
     for layer in (9,):

@@ -5,7 +5,7 @@ from audiopure_amd import synth, _native as N
 from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-modes = sys.argv[2:] or ["f32", "f32s", "f32h", "bf16"]
+modes = sys.argv[2:] or ["f32", "f32d", "f32s", "bf16"]
 L = 16000
 h = torch.randn(B, 256, L, device=dev); ho = torch.empty_like(h); sk = torch.zeros_like(h)
 pt = torch.randn(256, device=dev)
