@@ -158,3 +158,25 @@ def ddpm_spec_purify(model, img_db, t_star: int, noises, T=200, clip=True):
             else:
                 x = mean
         return melspec_inv_standardize(x)
+
+
+def conv3x3_minimal_filtering(x, w, b=None):
+    """nn.Conv2d(k = 3, stride 1, padding 1) of improved_diffusion/unet.py:60-104,150-197 in the F(2,3)-along-W form the HIP conv
+    kernel uses for these layers (audiopure_amd/csrc/ap_conv_w3.hip), same operation order: transformed weights computed in double
+    and rounded to fp32 once, input differences in fp32, fp32 products summed per product over (ky, ci), then
+    out[x0] = (m1 + m2) + m3, out[x0 + 1] = (m2 - m3) + m4'.  x: [B, Cin, H, W] with W even."""
+    B, Cin, H, W = x.shape
+    w64 = w.double()
+    G = [w64[..., 0], (w64[..., 0] + w64[..., 1] + w64[..., 2]) / 2, (w64[..., 0] - w64[..., 1] + w64[..., 2]) / 2, w64[..., 2]]
+    G = [g.float() for g in G]                                           # [Cout, Cin, 3 (ky)]
+    xp = F.pad(x, (1, 1, 1, 1))                                          # zero padding
+    rows = torch.stack([xp[:, :, ky:ky + H, :] for ky in range(3)], 2)   # [B, Cin, ky, H, W + 2]
+    d0, d1, d2, d3 = (rows[..., k:k + W:2] for k in range(4))            # columns x0 - 1 .. x0 + 2 of every pair (x0 even)
+    m1 = torch.einsum("ock,bckhp->bohp", G[0], d0 - d2)
+    m2 = torch.einsum("ock,bckhp->bohp", G[1], d1 + d2)
+    m3 = torch.einsum("ock,bckhp->bohp", G[2], d2 - d1)
+    m4 = torch.einsum("ock,bckhp->bohp", G[3], d3 - d1)
+    out = torch.empty(B, w.shape[0], H, W, dtype=x.dtype)
+    out[..., 0::2] = (m1 + m2) + m3
+    out[..., 1::2] = (m2 - m3) + m4
+    return out if b is None else out + b.view(1, -1, 1, 1)

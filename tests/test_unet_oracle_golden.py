@@ -83,3 +83,22 @@ def test_ddpm_chain_oracle_matches_reference_gaussian_diffusion(gold):
     z = [torch.from_numpy(synth.normal(f"sz{i}", (2, 1, 32, 32), 5)) for i in range(5)]
     got = U.ddpm_spec_purify(m, img, 4, z)
     assert rel_err(got.numpy(), gold["mini/ddpm_t4"]) < 5e-6
+
+
+def test_minimal_filtering_form_of_the_3x3_conv_is_the_conv():
+    """The F(2,3)-along-W form the HIP library runs the UNet's 3 x 3 convolutions in (ap_conv_w3.hip), restated on the CPU with the
+    kernel's operation order, equals nn.functional.conv2d at fp32 rounding for every map size the UNet has and for odd heights."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import unet_oracle as U
+    g = torch.Generator().manual_seed(3)
+    for (B, Cin, H, W, Cout) in [(2, 32, 32, 32, 16), (3, 16, 16, 16, 24), (2, 8, 8, 8, 8), (4, 8, 4, 4, 8), (1, 4, 5, 2, 3), (2, 4, 1, 6, 5)]:
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2
+        b = torch.randn(Cout, generator=g)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        got = U.conv3x3_minimal_filtering(x, w, b)
+        plain = F.conv2d(x, w, b, padding=1)
+        e_w = float((got.double() - ref).abs().max() / ref.abs().max())
+        e_p = float((plain.double() - ref).abs().max() / ref.abs().max())
+        assert e_w < 2e-6 and e_w < 4 * e_p + 2e-7, (B, Cin, H, W, Cout, e_w, e_p)
