@@ -197,7 +197,7 @@ def on_device(fn):
 
 
 _CONV_WS = {}                                    # device index -> the tensor the library's split-K path writes its partial sums to
-CONV_WS_BYTES = 64 << 20
+CONV_WS_BYTES = 128 << 20                        # (the K slices of the UNet's 8 x 8 maps at B = 256: 4 x 16.8 MB)
 
 
 def use_conv_workspace(device) -> None:

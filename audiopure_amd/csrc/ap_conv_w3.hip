@@ -27,10 +27,24 @@ bool conv_w3_serves(int Cin, int H, int W, int Cout, int kh, int kw, int stride,
 size_t conv_w3_elems(int Cout, int Cin) { return (size_t)4 * Cout * Cin * 3; }
 // persistent one-workgroup-per-CU kernel: worth it from two tiles per CU on (measured at B = 256: the UNet's 32 x 32 and 16 x 16 maps
 // 1.15-1.36 x faster than the direct kernels, its 8 x 8 / 4 x 4 maps -- 128 / 32 tiles -- 1.15-3 x slower: those keep the direct kernels)
-bool conv_w3_worth(int B, int H, int W, int Cout) {
+long long conv_w3_tiles(int B, int H, int W, int Cout) {
   const int rt = Cout % 256 == 0 ? 2 : 1, ncol = rt == 2 ? 64 : 128;
   const long long npairs = (long long)B * H * (W / 2);
-  return (long long)(Cout / (128 * rt)) * ((npairs + ncol - 1) / ncol) >= 512;
+  return (long long)(Cout / (128 * rt)) * ((npairs + ncol - 1) / ncol);
+}
+bool conv_w3_worth(int B, int H, int W, int Cout) { return conv_w3_tiles(B, H, W, Cout) >= 512; }
+// K slices for a layer with too few tiles (the UNet's 8 x 8 and 4 x 4 maps: 128 / 32 tiles): each slice sums its share of the
+// (ky, channel-block) chunks and writes its TRANSFORMED partial outputs (the output transform is linear) to the caller's
+// workspace; the conv launcher's reduce kernel adds the slices in order (deterministic), then bias / residual / ReLU.
+// 0: not worth it (under 32 tiles, or fewer than 3 chunks per slice)
+int conv_w3_splits(int B, int Cin, int H, int W, int Cout, size_t ws_bytes) {
+  const long long t = conv_w3_tiles(B, H, W, Cout);
+  if (t >= 512 || t < 32) return 0;
+  const int nch = 3 * (Cin / 32);
+  int S = 2;
+  while (S < 8 && t * S < 512) S *= 2;
+  while (S > 1 && (nch / S < 3 || (size_t)S * B * Cout * H * W * sizeof(float) > ws_bytes)) S /= 2;
+  return S > 1 ? S : 0;
 }
 // rows per workgroup: 256 (RT = 2 row tiles per wave) where Cout allows it, else 128 (RT = 1, four column tiles per wave)
 static int conv_w3_rt(int Cout) { return Cout % 256 == 0 ? 2 : 1; }
@@ -73,7 +87,9 @@ struct ConvW3Args {
   const float *x, *wimg, *bias, *res;
   float *out;
   int B, Cin, H, W, Cout, relu, x_cstride, x_coff, o_cstride, o_coff;
-  int npairs, ntile_n, nblk;     // pair columns B H W/2; column tiles; total tiles = row blocks x column tiles
+  int npairs, ntile_n, nblk;     // pair columns B H W/2; column tiles; total tiles = row blocks x column tiles x K slices
+  int splits;                    // > 1: K slices; raw transformed partial sums go to part [splits][B][Cout][H][W]
+  float *part;
 };
 
 // RT row tiles x CT column tiles per wave (RT CT = 4): workgroup tile = (128 RT rows) x (32 CT pair columns)
@@ -125,8 +141,12 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
 
 #pragma unroll 1
   for (int tile = t_first; tile < t_end; tile += t_step) {
-    const int rb = __builtin_amdgcn_readfirstlane(tile / a.ntile_n);
-    const int n0 = __builtin_amdgcn_readfirstlane((tile % a.ntile_n) * NCOL);
+    const int zs = __builtin_amdgcn_readfirstlane(tile % a.splits);            // K slice (fastest: the slices of an output tile run side by side)
+    const int tl = tile / a.splits;
+    const int rb = __builtin_amdgcn_readfirstlane(tl / a.ntile_n);
+    const int n0 = __builtin_amdgcn_readfirstlane((tl % a.ntile_n) * NCOL);
+    const int c0 = __builtin_amdgcn_readfirstlane((int)((long long)NCH * zs / a.splits));
+    const int c1 = __builtin_amdgcn_readfirstlane((int)((long long)NCH * (zs + 1) / a.splits));
     const __amdgpu_buffer_rsrc_t wrs =
         uni_rsrc(reinterpret_cast<const char *>(a.wimg) + ((size_t)rb * 4 + wave) * wave_bytes, wave_bytes);
     auto load_a = [&](f32x4(&aa)[RT], unsigned unit) {           // one (k-group, product) unit: RT row tiles
@@ -195,8 +215,8 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
 
     f32x4 aw[4][RT];
 #pragma unroll
-    for (int u = 0; u < 4; u++) load_a(aw[u], (unsigned)u);
-    issue_x(0);
+    for (int u = 0; u < 4; u++) load_a(aw[u], (unsigned)(16 * c0 + u));
+    issue_x(c0);
     f32x16 acc[4][RT][CT];
 #pragma unroll
     for (int c4 = 0; c4 < 4; c4++)
@@ -212,9 +232,9 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
     const float *xfrag = lds + j * ZSW_ + 4 * hh;
     const unsigned nunit = (unsigned)NCH * 16u;
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ch++) {
-      const float *xb = xfrag + (ch & 1) * XBUF;
-      issue_x(ch + 1 < NCH ? ch + 1 : ch);
+    for (int ch = c0; ch < c1; ch++) {
+      const float *xb = xfrag + ((ch - c0) & 1) * XBUF;
+      issue_x(ch + 1 < c1 ? ch + 1 : ch);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kg = 0; kg < 4; kg++) {
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
           f32x4 bq[CT];
 #pragma unroll
           for (int ct = 0; ct < CT; ct++) bq[ct] = *reinterpret_cast<const f32x4 *>(xb + comp * XCOMP + 32 * ct * ZSW_ + kg * 8);
-          if (u == 12) store_x(lds + ((ch + 1) & 1) * XBUF);
+          if (u == 12) store_x(lds + ((ch - c0 + 1) & 1) * XBUF);
 #pragma unroll
           for (int e = 0; e < 4; e++)
 #pragma unroll
@@ -269,6 +289,17 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
         const int co0 = 128 * RT * rb + 32 * RT * wave + 32 * rt + 4 * hh;
         const unsigned eo = nv ? (unsigned)((((size_t)bb * a.o_cstride + a.o_coff + co0) * HW + pix) * 4) : 0x80000000u;
         const unsigned er = nv ? (unsigned)((((size_t)bb * a.Cout + co0) * HW + pix) * 4) : 0x80000000u;
+        if (a.splits > 1) {                                     // raw partial of this K slice: [slice][B][Cout][H][W]
+          const __amdgpu_buffer_rsrc_t prs = uni_rsrc(a.part + (size_t)zs * a.B * a.Cout * HW, rbytes);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            const f32x2 o = {(acc[0][rt][ct][r] + acc[1][rt][ct][r]) + acc[2][rt][ct][r], (acc[1][rt][ct][r] - acc[2][rt][ct][r]) + acc[3][rt][ct][r]};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), prs, er, ro * HW * 4, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          continue;
+        }
         f32x2 rv[16];
         float bv[16];
 #pragma unroll
@@ -296,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
 static int g_ncu_w3 = 0;
 
 int launch_conv_w3(const float *x, const float *wimg, const float *bias, const float *res, float *out, int B, int Cin, int H, int W,
-                   int Cout, int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, hipStream_t st) {
+                   int Cout, int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, hipStream_t st, int splits, float *part) {
   if (g_ncu_w3 == 0) {
     int dev = 0, n = 0;
     AP_HIP(hipGetDevice(&dev));
@@ -311,7 +342,9 @@ int launch_conv_w3(const float *x, const float *wimg, const float *bias, const f
   a.npairs = B * H * (W / 2);
   const int ncol = RT == 2 ? 64 : 128;
   a.ntile_n = (a.npairs + ncol - 1) / ncol;
-  const long long nblk = (long long)(Cout / (128 * RT)) * a.ntile_n;
+  a.splits = splits > 1 ? splits : 1;
+  a.part = part;
+  const long long nblk = (long long)(Cout / (128 * RT)) * a.ntile_n * a.splits;
   a.nblk = (int)nblk;
   const unsigned grid = (unsigned)(nblk < g_ncu_w3 ? nblk : g_ncu_w3);
   if (RT == 2) conv2d_w3_kernel<2><<<grid, 256, 0, st>>>(a);

@@ -925,8 +925,10 @@ static int g_conv_wide_1x1 = 0;               // ap_debug_conv_path(2): pointwis
 static int g_conv_force = 0;                  // ap_debug_conv_path(4..7): every streamed-weight layer on 128x128 / 128x64 / 64x64 / 64x128 tiles; 8: off
 static int g_conv_w3 = 1;                     // ap_debug_conv_w3(on, min_pairs): the F(2,3) kernel for the layers it serves / the direct kernels
 static long long g_conv_w3_min_pairs = 0;
+static int g_conv_w3_split = 1;               // ap_debug_conv_w3(on + 4 * nosplit, ..): K slices for the low-resolution maps on / off
 extern "C" int ap_debug_conv_w3(int on, int min_pairs) {
-  g_conv_w3 = on;
+  g_conv_w3 = on & 3;
+  g_conv_w3_split = (on & 4) ? 0 : 1;
   g_conv_w3_min_pairs = min_pairs;
   return 0;
 }
@@ -952,16 +954,18 @@ static constexpr long long g_conv_splitk_t2 = 384;
 static constexpr int g_conv_splitk_cap = 768;
 static constexpr int g_conv_w3 = 1;
 static constexpr long long g_conv_w3_min_pairs = 0;
+static constexpr int g_conv_w3_split = 1;
 #endif
 
 // ap_conv_w3.hip: 3 x 3 / stride 1 / pad 1 / ungrouped layers in F(2,3) form along W; their transformed-weight image is the LAST image
 namespace ap {
 bool conv_w3_serves(int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups);
 bool conv_w3_worth(int B, int H, int W, int Cout);
+int conv_w3_splits(int B, int Cin, int H, int W, int Cout, size_t ws_bytes);
 size_t conv_w3_elems(int Cout, int Cin);
 int launch_conv_pack_w3(const float *w, const float *scale, float *out, int Cout, int Cin, hipStream_t st);
 int launch_conv_w3(const float *x, const float *wimg, const float *bias, const float *res, float *out, int B, int Cin, int H, int W,
-                   int Cout, int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, hipStream_t st);
+                   int Cout, int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, hipStream_t st, int splits = 1, float *part = nullptr);
 }
 static bool conv_has_w3(int Cout, int Cin_g, int kh, int kw, int groups) {
   return conv_w3_serves(Cin_g, 4, 4, Cout, kh, kw, 1, 1, groups);      // the weight-side conditions (kernel 3 x 3, ungrouped, Cin % 32, Cout % 128)
@@ -1193,10 +1197,27 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
   }
   if (g_conv_w3 && !split && !splith && !one_d && dil == 1 && conv_w3_serves(Cin, H, W, Cout, kh, kw, stride, pad, groups) &&
       (size_t)B * x_cstride * H * W * sizeof(float) < ((size_t)1 << 31) && (size_t)B * a.o_cstride * H * W * sizeof(float) < ((size_t)1 << 31) &&
-      (g_conv_w3 == 2 || conv_w3_worth(B, H, W, Cout)) && (long long)B * H * (W / 2) >= g_conv_w3_min_pairs) {   // (g_conv_w3 == 2, tools: every served layer)
-    *cls = 6;
-    return launch_conv_w3(x, wT + conv_w3_offset(Cout, Cin, kh, kw, groups), bias, res, out, B, Cin, H, W, Cout, relu, x_cstride, x_coff,
-                          a.o_cstride, a.o_coff, (hipStream_t)stream);
+      (long long)B * H * (W / 2) >= g_conv_w3_min_pairs) {
+    const float *wimg = wT + conv_w3_offset(Cout, Cin, kh, kw, groups);
+    if (g_conv_w3 == 2 || conv_w3_worth(B, H, W, Cout)) {       // (g_conv_w3 == 2, tools: every served layer, unsliced)
+      *cls = 6;
+      return launch_conv_w3(x, wimg, bias, res, out, B, Cin, H, W, Cout, relu, x_cstride, x_coff, a.o_cstride, a.o_coff, (hipStream_t)stream);
+    }
+    // too few tiles for one workgroup per CU (the UNet's 8 x 8 and 4 x 4 maps): K slices into the caller's workspace, summed in
+    // order by the reduce kernel (which also adds bias / residual / ReLU) -- deterministic
+    const ConvWs cws = g_conv_w3_split ? conv_ws_here() : ConvWs{};
+    const int S = cws.p ? conv_w3_splits(B, Cin, H, W, Cout, cws.bytes) : 0;
+    if (S > 1) {
+      *cls = 6;
+      int rc = launch_conv_w3(x, wimg, nullptr, nullptr, out, B, Cin, H, W, Cout, 0, x_cstride, x_coff, a.o_cstride, a.o_coff, (hipStream_t)stream, S, cws.p);
+      if (rc) return rc;
+      a.splits = S;
+      a.part = cws.p;
+      const size_t total = (size_t)B * Cout * a.Ho * a.Wo;
+      conv_splitk_reduce_kernel<<<(unsigned)((total / 4 + 255) / 256 + 1), 256, 0, (hipStream_t)stream>>>(a, total);
+      AP_HIP(hipGetLastError());
+      return 0;
+    }
   }
   if (conv_has_frag(Cout, Cin / groups, groups) && !g_conv_no_frag) {
     const size_t n1 = (size_t)Cout * (Cin / groups) * kh * kw;

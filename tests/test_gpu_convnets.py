@@ -226,7 +226,10 @@ def test_conv3x3_minimal_filtering_kernel_matches_conv2d(dev):
     lib = N.lib()
     # (the launcher takes this kernel from 512 tiles on: B sized so that every case has them -- small maps need many images)
     cases = [(2050, 32, 8, 8, 128, True, True, 1), (4100, 64, 4, 4, 256, True, False, 0), (260, 128, 32, 32, 128, False, True, 1), (258, 32, 16, 16, 256, True, True, 0),
-             (33000, 32, 2, 2, 128, True, False, 0), (1101, 96, 6, 10, 384, True, True, 1), (2731, 32, 3, 4, 512, False, False, 1)]
+             (33000, 32, 2, 2, 128, True, False, 0), (1101, 96, 6, 10, 384, True, True, 1), (2731, 32, 3, 4, 512, False, False, 1),
+             # 32 .. 511 tiles: K slices into the split-K workspace + the reduce kernel (the UNet's 8 x 8 / 4 x 4 maps at B = 256)
+             (256, 256, 8, 8, 256, True, True, 1), (256, 256, 4, 4, 256, True, False, 0), (300, 96, 8, 8, 128, False, True, 1), (301, 512, 4, 4, 256, True, True, 0)]
+    N.use_conv_workspace(dev)
     for (B, Cin, H, W, Cout, has_b, has_r, relu) in cases:
         x = torch.from_numpy(synth.uniform(f"w3x{Cin}{H}{W}", (B, Cin + 5, H, W), 1)).to(dev)       # the conv reads channels [3, 3 + Cin)
         w = torch.from_numpy(synth.uniform(f"w3w{Cin}{Cout}", (Cout, Cin, 3, 3), 1)).to(dev) * 0.1
@@ -247,7 +250,7 @@ def test_conv3x3_minimal_filtering_kernel_matches_conv2d(dev):
         N.check(lib.ap_conv_profile_read(ms, fl, n, 8))
         N.check(lib.ap_conv_profile_enable(0))
         assert n[6] == 1, (list(n), "the F(2,3) kernel did not take this layer")
-        assert rel_err(out.cpu().numpy(), ref.float().cpu().numpy()) < 2e-6, (B, Cin, H, W, Cout)
+        assert rel_err(out.cpu().numpy(), ref.float().cpu().numpy()) < 3e-6, (B, Cin, H, W, Cout)
         wide = torch.full((B, Cout + 7, H, W), 4.0, device=dev)                                       # out = channels [2, 2 + Cout) of a wider tensor
         N.check(lib.ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(r), N.ptr(wide), B, Cin, H, W, Cout, 3, 3, 1, 1, 1, relu, Cin + 5, 3,
                                         Cout + 7, 2, N.stream()))
