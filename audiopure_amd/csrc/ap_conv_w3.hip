@@ -93,8 +93,13 @@ struct ConvW3Args {
 };
 
 // RT row tiles x CT column tiles per wave (RT CT = 4): workgroup tile = (128 RT rows) x (32 CT pair columns)
-template <int RT>
+// NB (W / 2 a power of two <= 64: every map of the UNet): a wave's 64 staging lanes are whole image rows of consecutive pairs, so a
+// lane loads only its own two columns (x0, x0 + 1: one aligned 8-byte load) and takes x0 - 1 / x0 + 2 from its neighbours' registers
+// (v_mov_b32_dpp wave_shr / wave_shl; zero at the row's ends) -- a quarter of the gather's load instructions.
+template <int RT, bool NB>
 __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   constexpr int CT = 4 / RT, NCOL = 32 * CT;
   constexpr int XCOMP = NCOL * ZSW_, XBUF = 4 * XCOMP;
   __shared__ __attribute__((aligned(16))) float lds[2 * XBUF];   // RT = 2: 72 KB, RT = 1: 144 KB
@@ -172,14 +177,23 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
                        : 0x80000000u;
       }
     }
-    float xr[QP][4][4];                                         // [quad pass][channel][tap]
+    float xr[NB ? 1 : QP][4][4];                                // [quad pass][channel][tap]  (gather form)
+    f32x2 xn[NB ? QP : 1][4];                                   // [quad pass][channel] columns (x0, x0 + 1)  (neighbour form)
     auto issue_x = [&](int ch) {
       const int ky = ch / CB, cb = ch - ky * CB;
       const unsigned v = ky == 0 ? vrow[0] : ky == 1 ? vrow[1] : vrow[2];
       const bool rok = v != 0x80000000u;                         // (the input row is inside the image)
+      if constexpr (NB) {
+#pragma unroll
+        for (int ps = 0; ps < QP; ps++)
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++)
+            xn[ps][cc] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, v, (32 * cb + 4 * TPC * ps + cc) * HW * 4, 0));
+        return;
+      }
       const unsigned vl = (okl && rok) ? v - 4u : 0x80000000u, vr = (okr && rok) ? v + 8u : 0x80000000u, vm = rok ? v + 4u : 0x80000000u;
 #pragma unroll
-      for (int ps = 0; ps < QP; ps++)
+      for (int ps = 0; ps < (NB ? 1 : QP); ps++)
 #pragma unroll
         for (int cc = 0; cc < 4; cc++) {
           const int so = (32 * cb + 4 * TPC * ps + cc) * HW * 4;
@@ -192,16 +206,32 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
     auto store_x = [&](float *dst) {
 #pragma unroll
       for (int ps = 0; ps < QP; ps++) {
-        asm volatile("" : "+v"(xr[ps][0][0]), "+v"(xr[ps][0][1]), "+v"(xr[ps][0][2]), "+v"(xr[ps][0][3]), "+v"(xr[ps][1][0]), "+v"(xr[ps][1][1]),
-                     "+v"(xr[ps][1][2]), "+v"(xr[ps][1][3]), "+v"(xr[ps][2][0]), "+v"(xr[ps][2][1]), "+v"(xr[ps][2][2]), "+v"(xr[ps][2][3]),
-                     "+v"(xr[ps][3][0]), "+v"(xr[ps][3][1]), "+v"(xr[ps][3][2]), "+v"(xr[ps][3][3]));
         f32x4 c0, c1, c2, c3;
+        if constexpr (NB) {
+          asm volatile("" : "+v"(xn[ps][0]), "+v"(xn[ps][1]), "+v"(xn[ps][2]), "+v"(xn[ps][3]));
 #pragma unroll
-        for (int cc = 0; cc < 4; cc++) {
-          c0[cc] = xr[ps][cc][0] - xr[ps][cc][2];
-          c1[cc] = xr[ps][cc][1] + xr[ps][cc][2];
-          c2[cc] = xr[ps][cc][2] - xr[ps][cc][1];
-          c3[cc] = xr[ps][cc][3] - xr[ps][cc][1];
+          for (int cc = 0; cc < 4; cc++) {
+            const float d1 = xn[ps][cc][0], d2 = xn[ps][cc][1];
+            // lane i's x0 - 1 is lane i - 1's x0 + 1, its x0 + 2 is lane i + 1's x0 (same image row; zero at the row's ends)
+            const float fl = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d2), 0x138, 0xf, 0xf, true));
+            const float fr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d1), 0x130, 0xf, 0xf, true));
+            const float d0 = okl ? fl : 0.f, d3 = okr ? fr : 0.f;
+            c0[cc] = d0 - d2;
+            c1[cc] = d1 + d2;
+            c2[cc] = d2 - d1;
+            c3[cc] = d3 - d1;
+          }
+        } else {
+          asm volatile("" : "+v"(xr[ps][0][0]), "+v"(xr[ps][0][1]), "+v"(xr[ps][0][2]), "+v"(xr[ps][0][3]), "+v"(xr[ps][1][0]), "+v"(xr[ps][1][1]),
+                       "+v"(xr[ps][1][2]), "+v"(xr[ps][1][3]), "+v"(xr[ps][2][0]), "+v"(xr[ps][2][1]), "+v"(xr[ps][2][2]), "+v"(xr[ps][2][3]),
+                       "+v"(xr[ps][3][0]), "+v"(xr[ps][3][1]), "+v"(xr[ps][3][2]), "+v"(xr[ps][3][3]));
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) {
+            c0[cc] = xr[ps][cc][0] - xr[ps][cc][2];
+            c1[cc] = xr[ps][cc][1] + xr[ps][cc][2];
+            c2[cc] = xr[ps][cc][2] - xr[ps][cc][1];
+            c3[cc] = xr[ps][cc][3] - xr[ps][cc][1];
+          }
         }
         float *q = dst + sj * ZSW_ + 4 * TPC * ps + 4 * sq;
         *reinterpret_cast<f32x4 *>(q) = c0;
@@ -256,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, QP == 2 ? 3 : 5, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, (QP == 2 ? 3 : 5) + (NB ? QP : 0), 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x200, 4 * QP, 0);
           }
@@ -275,8 +305,6 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
     // ---- output transform, bias, residual, ReLU; lane (j, hh) of column tile ct holds pair column n0 + 32 ct + j, rows crowoff
     const __amdgpu_buffer_rsrc_t ors = uni_rsrc(a.out, obytes);
     const __amdgpu_buffer_rsrc_t rrs = uni_rsrc(a.res ? a.res : a.out, a.res ? rbytes : 0u);
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -325,6 +353,11 @@ __global__ __launch_bounds__(256, 1) void conv2d_w3_kernel(ConvW3Args a) {
 }
 
 static int g_ncu_w3 = 0;
+#ifdef AP_TOOLS
+static int g_w3_nb = 1;
+#else
+static constexpr int g_w3_nb = 1;
+#endif
 
 int launch_conv_w3(const float *x, const float *wimg, const float *bias, const float *res, float *out, int B, int Cin, int H, int W,
                    int Cout, int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, hipStream_t st, int splits, float *part) {
@@ -347,10 +380,24 @@ int launch_conv_w3(const float *x, const float *wimg, const float *bias, const f
   const long long nblk = (long long)(Cout / (128 * RT)) * a.ntile_n * a.splits;
   a.nblk = (int)nblk;
   const unsigned grid = (unsigned)(nblk < g_ncu_w3 ? nblk : g_ncu_w3);
-  if (RT == 2) conv2d_w3_kernel<2><<<grid, 256, 0, st>>>(a);
-  else conv2d_w3_kernel<1><<<grid, 256, 0, st>>>(a);
+  const int w2 = W / 2;
+  const bool nb = g_w3_nb && w2 <= 64 && (w2 & (w2 - 1)) == 0;    // whole image rows per 64 staging lanes: the neighbour form
+  if (RT == 2) {
+    if (nb) conv2d_w3_kernel<2, true><<<grid, 256, 0, st>>>(a);
+    else conv2d_w3_kernel<2, false><<<grid, 256, 0, st>>>(a);
+  } else {
+    if (nb) conv2d_w3_kernel<1, true><<<grid, 256, 0, st>>>(a);
+    else conv2d_w3_kernel<1, false><<<grid, 256, 0, st>>>(a);
+  }
   AP_HIP(hipGetLastError());
   return 0;
 }
 
 }  // namespace ap
+
+#ifdef AP_TOOLS
+extern "C" int ap_debug_conv_w3_nb(int on) {                     // A/B: the neighbour staging form on / off
+  ap::g_w3_nb = on;
+  return 0;
+}
+#endif
