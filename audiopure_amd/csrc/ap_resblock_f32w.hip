@@ -39,7 +39,10 @@ constexpr int XCOMP_ = NP_ * XS_;        // one product's image
 constexpr int XBUF_ = 4 * XCOMP_;        // one chunk's image (18 KB)
 constexpr int GS_ = WC_ + 4;             // floats per column row of the g image
 constexpr int GOFF_ = 2 * XBUF_;
+constexpr int POFF_ = GOFF_ + 64 * GS_;         // Q16: output patches, [wave 4][2][32 rows][36] floats (36.9 KB)
+constexpr int PS_ = 36;
 constexpr int LDS_FLOATS_ = GOFF_ + 64 * GS_;   // 103,424 B
+constexpr int LDS_FLOATS_Q16_ = POFF_ + 4 * 2 * 32 * PS_;   // 140,288 B
 constexpr unsigned UNIT_BYTES_ = 4 * 64 * 16;   // one (k-group, product) unit of a wave's GEMM1 image: 4 row tiles x 64 lanes x 16 B
 constexpr unsigned W1W_WAVE_BYTES_ = NCH_ * 4 * 4 * UNIT_BYTES_;   // 512 KB per wave and layer
 constexpr unsigned W2W_WAVE_BYTES_ = (WC_ / 8) * UNIT_BYTES_;      // 128 KB per wave and layer
@@ -90,7 +93,12 @@ int launch_pack_f32w(ap_ctx *ctx, hipStream_t st) {
 
 // SAVE (the differentiable path's forward pass, ap_resblock_fwd_save): the pre-gate activations y = DilConv(u) + b are also written
 // to aout [B][2C][L] (rows 0..C-1 the tanh half, C..2C-1 the sigmoid half: what ap_resblock_bwd reads).
-template <bool NOH, int ABL = 0, bool SAVE = false>
+// Q16 (clip lengths that are multiples of four -- every shipped shape): the epilogue goes through wave-private LDS patches so that
+// each 32 x 32 accumulator tile leaves as 1 row x 4 samples per lane -- 16-byte stores, the residual's h patch and the running skip
+// rows as 16-byte loads (skip += as a read-modify-write: one workgroup owns a tile within a launch, launches are stream-ordered,
+// so the sum is as deterministic as the float atomics of the 4-byte form).  A CU's store path moves a 4-byte-per-lane store
+// stream at a fraction of its 16-byte rate: the 4-byte epilogue cost 6.5 % of the launch (tools/ablate_f32w.py).
+template <bool NOH, int ABL = 0, bool SAVE = false, bool Q16 = false>
 __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1w, const float *__restrict__ b1, const float *__restrict__ w2w,
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
   // 8 X loads of the chunk loop, 16 GEMM1 weight loads, 32 staging transform + LDS writes, 64 per-chunk barrier, 128 GEMM1 MFMAs,
   // 256 GEMM2 MFMAs, 512 GEMM2 weight loads
   constexpr int C = WC_;
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS_];
+  __shared__ __attribute__((aligned(16))) float lds[Q16 ? LDS_FLOATS_Q16_ : LDS_FLOATS_];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -368,12 +376,32 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     // The residual's h patch (this wave's 64 res rows x 64 columns) is requested now -- behind the first weight groups, so that
     // their waits do not include it -- and consumed after GEMM2: the epilogue never waits on memory.
     __builtin_amdgcn_sched_barrier(0);
-    float hres[2][2][16];
-    if (ablate & 4) {
+    float hres[Q16 ? 1 : 2][Q16 ? 1 : 2][16];
+    f32x4 hq[Q16 ? 2 : 1][Q16 ? 2 : 1][4];                      // Q16: [res row tile][column tile][row octet p]: row l / 8 + 8 p, samples 4 (l % 8) ..
+    unsigned eo4[2] = {0x80000000u, 0x80000000u};
+    if constexpr (Q16) {
+      const int rowq = lane >> 3, cq = lane & 7;
+#pragma unroll
+      for (int ct = 0; ct < 2; ct++) {
+        const int t = tfirst + (ct ? (d >= 32 ? d : 32) : 0) + 4 * cq;
+        eo4[ct] = t < L ? ((unsigned)(64 * wave + rowq) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
+      }
+      if (!NOH) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+              hq[rt][ct][p] = (ablate & 4) ? f32x4{0.f, 0.f, 0.f, 0.f}
+                                           : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, eo4[ct], (32 * rt + 8 * p) * L * 4, 2));
+      }
+    }
+    if (!Q16 && (ablate & 4)) {
 #pragma unroll
       for (int i = 0; i < 64; i++) (&hres[0][0][0])[i] = 0.f;
     }
-    if (!NOH && !(ablate & 4)) {
+    if (!Q16 && !NOH && !(ablate & 4)) {
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -410,12 +438,71 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
       }
     }
 
+    const __amdgpu_buffer_rsrc_t ors = uni_rsrc((NOH ? skip : hout) + (size_t)b * C * L, clip_bytes);
+    const __amdgpu_buffer_rsrc_t srs = uni_rsrc(skip + (size_t)b * C * L, clip_bytes);     // S == C
+    if constexpr (Q16) {
+      // ---- 16-byte epilogue (WaveNet.py:97, :133).  Order: the running skip rows are requested, the res tiles leave (h'), the NEXT
+      // tile's first weights and X chunk are requested, the skip tiles leave -- so the next tile's first wait has only the 16 skip
+      // stores behind its loads (vmcnt retires in order).
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const float RS = 0.707106781186547524f;   // float(math.sqrt(0.5))
+      f32x4 sk4[2][2][4];
+      if (accumulate) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+              sk4[rt][ct][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srs, eo4[ct], (32 * rt + 8 * p) * L * 4, 2));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) (&sk4[0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      float *patch0 = lds + POFF_ + wave * (2 * 32 * PS_);
+      const int rowq = lane >> 3, cq = lane & 7;
+      auto leave = [&](int k, const f32x16 &tile, auto &&out4) {  // accumulator tile -> patch k & 1 -> 4 x (row, 4 samples) per lane
+        float *patch = patch0 + (k & 1) * (32 * PS_);
+#pragma unroll
+        for (int r = 0; r < 16; r++) patch[rowoff(r, hh) * PS_ + j] = tile[r];
+#pragma unroll
+        for (int p = 0; p < 4; p++) out4(p, *reinterpret_cast<const f32x4 *>(patch + (rowq + 8 * p) * PS_ + 4 * cq));
+      };
+      if (!(ablate & 2) || accumulate == 0x12345) {
+        if (!NOH) {
+#pragma unroll
+          for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+            for (int ct = 0; ct < 2; ct++)
+              leave(2 * rt + ct, acc2[rt][ct], [&](int p, f32x4 v) {
+                const f32x4 o = (hq[rt][ct][p] + v) * RS;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ors, eo4[ct], (32 * rt + 8 * p) * L * 4, 2);
+              });
+        }
+      }
+      if (!(ablate & 2048)) {
+        set_tile(tile + t_step < t_end ? tile + t_step : tile);  // (the last tile re-requests itself, unused)
+#pragma unroll
+        for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
+        issue_x(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(ablate & 2) || accumulate == 0x12345) {
+#pragma unroll
+        for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+          for (int ct = 0; ct < 2; ct++)
+            leave(2 * rt + ct, acc2[2 + rt][ct], [&](int p, f32x4 v) {
+              const f32x4 o = sk4[rt][ct][p] + v;
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), srs, eo4[ct], (32 * rt + 8 * p) * L * 4, 2);
+            });
+      }
+      continue;
+    }
     // ---- the NEXT tile's first weights and first chunk of X are requested here, ahead of this tile's stores: vmcnt retires in
     // order, so requested after them their wait would include the 64 float atomics (thousands of cycles each to retire with every
     // CU issuing them); requested before, it includes at most the plain h' stores (the counter holds 63: the wait for these loads
     // lets the youngest 63 operations -- the atomics -- stay outstanding)
-    const __amdgpu_buffer_rsrc_t ors = uni_rsrc((NOH ? skip : hout) + (size_t)b * C * L, clip_bytes);
-    const __amdgpu_buffer_rsrc_t srs = uni_rsrc(skip + (size_t)b * C * L, clip_bytes);     // S == C
     if (!(ablate & 2048)) {
       set_tile(tile + t_step < t_end ? tile + t_step : tile);    // (the last tile re-requests itself, unused)
 #pragma unroll
@@ -463,6 +550,9 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 static int g_ncu = 0;
 #ifdef AP_TOOLS
 static int g_ablate_f32w = 0;
+static int g_no_q16 = 0;                                        // ap_debug_f32w_q16(0): the 4-byte epilogue for every clip length (A/B)
+#else
+static constexpr int g_no_q16 = 0;
 #endif
 
 bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L) {
@@ -493,15 +583,19 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
   const float *b1 = ctx->b1 + (size_t)layer * 2 * C;
   const float *b2 = ctx->b2 + (size_t)layer * (C + S);
   const unsigned grid = (unsigned)(nblk < g_ncu ? nblk : g_ncu);
+  const bool q16 = (L & 3) == 0 && !g_no_q16;
   if (aout) {
     if (!hout) { set_error("resblock (save): needs an h' buffer"); return -22; }
-    resblock_f32w_kernel<false, 0, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
+    if (q16) resblock_f32w_kernel<false, 0, true, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
+    else resblock_f32w_kernel<false, 0, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
     AP_HIP(hipGetLastError());
     return 0;
   }
 #define AP_F32W(ABL)                                                                                                           \
   do {                                                                                                                         \
-    if (hout) resblock_f32w_kernel<false, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
+    if (hout && q16) resblock_f32w_kernel<false, ABL, false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
+    else if (hout) resblock_f32w_kernel<false, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
+    else if (q16) resblock_f32w_kernel<true, ABL, false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
     else resblock_f32w_kernel<true, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);      \
   } while (0)
 #ifdef AP_TOOLS
@@ -536,6 +630,10 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
 }  // namespace ap
 
 #ifdef AP_TOOLS
+extern "C" int ap_debug_f32w_q16(int on) {
+  ap::g_no_q16 = on ? 0 : 1;
+  return 0;
+}
 extern "C" int ap_debug_ablate_f32w(int mask) {
   ap::g_ablate_f32w = mask;
   return 0;

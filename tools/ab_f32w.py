@@ -41,10 +41,14 @@ def main():
         lib.ap_debug_ablate_f32w(0)
         return e0.elapsed_time(e1) / n
 
+    lib.ap_debug_f32w_q16.argtypes = [C.c_int]
     for rep in range(2):
         for layer in (0, 5, 11):
             row = [t(layer, m) for m in masks]
-            print(f"layer {layer:2d}  " + "  ".join(f"mask {m}: {ms:7.3f} ms" for m, ms in zip(masks, row)), flush=True)
+            lib.ap_debug_f32w_q16(0)
+            t4 = t(layer, 0)
+            lib.ap_debug_f32w_q16(1)
+            print(f"layer {layer:2d}  " + "  ".join(f"mask {m}: {ms:7.3f} ms" for m, ms in zip(masks, row)) + f"   4-byte epilogue: {t4:7.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
