@@ -60,6 +60,8 @@ SIGNATURES = {
     "ap_resblock_fwd_save": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_resblock_bwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "ap_resblock_bwd_available": (_i, [_vp, _i, _i]),
+    "ap_resblock_bwd_bf16": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _vp, _fp, _i, _i, _vp]),
+    "ap_resblock_bwd_bf16_available": (_i, [_vp, _i, _i]),
     "ap_resblock_fwd_gate": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "ap_skip_gemm": (_i, [_vp, _i, _i, _vp, _fp, _i, _i, _i, _vp]),
     "ap_ctx_set_skip_group": (_i, [_vp, _i]),

@@ -104,6 +104,7 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->slab_w = nullptr;
   c->w1w = c->w2w = nullptr;
   c->slab_b = nullptr;
+  c->slab_bb = nullptr;
   c->w2t = c->w1b = nullptr;
   c->f32_form = 1;
   c->w1p_s = c->w2p_s = nullptr;
@@ -141,6 +142,7 @@ extern "C" int ap_ctx_destroy(ap_ctx *ctx) {
   if (ctx->slab_s) (void)hipFree(ctx->slab_s);
   if (ctx->slab_w) (void)hipFree(ctx->slab_w);
   if (ctx->slab_b) (void)hipFree(ctx->slab_b);
+  if (ctx->slab_bb) (void)hipFree(ctx->slab_bb);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   delete ctx;
   return 0;
@@ -284,6 +286,11 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
     (void)hipFree(ctx->slab_b);
     ctx->slab_b = nullptr;
     ctx->w2t = ctx->w1b = nullptr;
+  }
+  if (ctx->slab_bb) {
+    AP_HIP(hipStreamSynchronize(st));
+    (void)hipFree(ctx->slab_bb);
+    ctx->slab_bb = nullptr;
   }
   if (c.precision == AP_PREC_BF16) {
     const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;

@@ -85,6 +85,7 @@ struct ap_ctx {
   void *slab_w;
   float *w2t, *w1b;         // backward images of ap_resblock_bwd.hip (allocated at the first backward call), own allocation
   void *slab_b;
+  void *slab_bb;            // bf16 backward images of ap_resblock_bwd_bf16.hip (allocated at the first bf16 backward call)
   int f32_form;             // AP_PREC_F32: 1 = minimal-filtering (Winograd) block where built (default), 0 = direct-form block
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)

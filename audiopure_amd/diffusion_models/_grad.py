@@ -14,7 +14,8 @@ chain fits a memory budget (``SAVE_BUDGET_BYTES``; 288 GB of HBM hold a PGD batc
 ``J_eps^T v`` runs on the HIP library.  Shipped shape (res = skip = 256 channels), fp32: the forward keeps the pre-gate
 activations (``ap_resblock_fwd_save``) and a block's backward is ``ap_resblock_bwd`` -- two fused launches (the gate's
 derivative behind ``W2^T [dh'; dskip]``, then the transposed dilated conv in F(2,3) form with the residual path in its
-epilogue): the forward block's flops, no elementwise glue.  Every other shape / arithmetic mode: the residual blocks'
+epilogue): the forward block's flops, no elementwise glue.  bf16 mode at the same shape: ``ap_resblock_bwd_bf16`` -- two launches per
+layer on the bf16 matrix pipe from the layer inputs (the dilated conv recomputed inside).  Every other shape / arithmetic mode: the residual blocks'
 forward is the fused kernel (``ap_resblock_fwd``), the three GEMM-shaped backward terms of a block -- the recomputed dilated conv, ``W2^T [dh'; dskip]`` and the transposed
 dilated conv -- are ``ap_conv2d_fwd`` calls in ``AP_CONV_1D`` mode (MFMA conv-as-GEMM, weights streamed as
 fragments), with ``ap_gate_bwd`` / ``ap_relu_outer_bwd`` / ``ap_init_conv_bwd`` between them.  Gradients with respect
@@ -39,6 +40,7 @@ class EpsGrad:
     def __init__(self, net):
         self.net = net
         self._key = None
+        self.fused_bf16 = True          # tools/check_bwd_bf16.py turns it off to time / compare the composed fp32 backward in bf16 mode
 
     # ---- weights ---------------------------------------------------------------------------------------
     def _prepare(self):
@@ -166,6 +168,18 @@ class EpsGrad:
             for n in range(NL - 1, -1, -1):
                 N.check(lib.ap_resblock_bwd(eng.ctx, n, N.ptr(dh), N.ptr(dskip), N.ptr(pre[n]), N.ptr(dy), N.ptr(dh2), B, L, st),
                         "ap_resblock_bwd")
+                dh, dh2 = dh2, dh
+            dx = torch.empty((B, 1, L), device=dev)
+            N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")
+            return dx
+        if pre is None and self.fused_bf16 and self.net._precision == N.AP_PREC_BF16 and lib.ap_resblock_bwd_bf16_available(eng.ctx, B, L):
+            # bf16 mode at the shipped shape: two launches per layer on the bf16 matrix pipe (ap_resblock_bwd_bf16.hip) from the layer
+            # INPUTS the forward pass wrote anyway -- the dilated conv is recomputed inside the first kernel
+            dy = torch.empty((B, L, 2 * C_), device=dev, dtype=torch.bfloat16)
+            dh2 = torch.empty_like(dh)
+            for n in range(NL - 1, -1, -1):
+                N.check(lib.ap_resblock_bwd_bf16(eng.ctx, n, N.ptr(hs[n]), N.ptr(part[n * C_:(n + 1) * C_]), N.ptr(dh), N.ptr(dskip),
+                                                 dy.data_ptr(), N.ptr(dh2), B, L, st), "ap_resblock_bwd_bf16")
                 dh, dh2 = dh2, dh
             dx = torch.empty((B, 1, L), device=dev)
             N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")

@@ -221,6 +221,14 @@ int ap_resblock_fwd_save(ap_ctx *ctx, int layer, const float *h_in, const float 
 int ap_resblock_bwd(ap_ctx *ctx, int layer, const float *dh_out, const float *dskip, const float *pre_gate, float *dy_scratch,
                     float *dh_in, int B, int L, void *stream);
 int ap_resblock_bwd_available(ap_ctx *ctx, int B, int L);
+/* The same gradient in AP_PREC_BF16 (bf16 MFMA operands, fp32 accumulate), from the layer INPUT instead of kept pre-gate activations --
+ * on the bf16 matrix pipe the dilated conv is cheaper to recompute than a [B][2C][L] fp32 store per layer is to write:
+ *   y = DilConv(bf16(h_in + part_t)) + b;  dy = gate'(y) . ([W_res sqrt(1/2); W_skip]^T [dh_out; dskip])  -> dy_scratch: a bf16 image
+ *   [B][L][2C] (B L 1024 bytes);   dh_in = sqrt(1/2) dh_out + DilConv^T(dy).
+ * AP_PREC_BF16 contexts, res = skip = 256 channels. */
+int ap_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, const float *dh_out, const float *dskip,
+                         void *dy_scratch, float *dh_in, int B, int L, void *stream);
+int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L);
 
 int ap_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out,
                     float ca, float cb, float cs, const float *z, uint64_t seed, uint32_t draw,

@@ -459,3 +459,78 @@ def test_fused_block_backward_matches_autograd_through_the_oracle(dev, L, layer)
     ghd, gsd = gh.to(dev), gs.to(dev)                            # (held: a temporary's block would be reused by the next .to())
     N.check(lib.ap_resblock_bwd(eng.ctx, layer, N.ptr(ghd), N.ptr(gsd), N.ptr(pre), N.ptr(dy), N.ptr(dh_in), B, L, N.stream()))
     assert rel_err(dh_in.cpu().numpy(), g_ref.numpy()) < 1e-5
+
+
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("L,layer", [(1100, 0), (2048, 5), (1000, 11), (16000, 6), (130, 3), (77, 9), (64, 4), (4100, 10), (16000, 1)])
+def test_bf16_block_backward_matches_autograd_through_the_bf16_oracle(dev, L, layer):
+    """ap_resblock_bwd_bf16 (bf16 MFMA operands, the dilated conv recomputed from the layer input) against
+    torch autograd through the bf16-emulating oracle block (both forward GEMMs see bf16-rounded operands; its backward multiplies
+    the same rounded weights with fp32 cotangents): cosine >= 0.999 and max deviation <= 2e-2 of the largest gradient entry."""
+    from oracle import diffwave_oracle as O
+    from audiopure_amd import _native as N
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    net.set_precision("bf16")
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    lib = eng.lib
+    B, C_, d = 2, 256, 2 ** (layer % 12)
+    assert lib.ap_resblock_bwd_bf16_available(eng.ctx, B, L) == 1
+    h = torch.from_numpy(synth.uniform(f"gh/{L}", (B, C_, L), 1, -1.5, 1.5))
+    gh = torch.from_numpy(synth.uniform(f"gg/{L}", (B, C_, L), 2, -1.0, 1.0))
+    gs = torch.from_numpy(synth.uniform(f"gs/{L}", (B, C_, L), 3, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    p = f"residual_layer.residual_blocks.{layer}"
+    hr = h.clone().requires_grad_(True)
+    h_ref, s_ref = O.residual_block(w, layer, d, hr, emb, bf16_operands=True)
+    (g_ref,) = torch.autograd.grad([h_ref, s_ref], hr, [gh, gs])
+    with torch.no_grad():
+        part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+    hd, ptd, ghd, gsd = h.to(dev), part_t.to(dev).contiguous(), gh.to(dev), gs.to(dev)
+    dy = torch.zeros((B, L, 2 * C_), device=dev, dtype=torch.bfloat16)
+    dh_in = torch.full_like(hd, 5.0)
+    N.check(lib.ap_resblock_bwd_bf16(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ghd), N.ptr(gsd), dy.data_ptr(), N.ptr(dh_in), B, L, N.stream()))
+    got = dh_in.cpu()
+    assert torch.isfinite(got).all()
+    assert _cos(got, g_ref) >= 0.999, (_cos(got, g_ref),)
+    assert rel_err(got.numpy(), g_ref.numpy()) <= 2e-2
+
+
+def test_bf16_eps_vjp_runs_on_the_bf16_backward_and_matches_the_bf16_oracle(dev):
+    """The whole eps VJP in bf16 mode (forward: the bf16 block keeping layer inputs; backward: ap_resblock_bwd_bf16 per layer).
+    (1) Against the composed fp32 backward on the SAME stored layer inputs -- the backward kernels' own error through six layers:
+    cosine >= 0.9999, max deviation <= 2e-2 of the largest entry (the per-block bar).
+    (2) Against autograd through the bf16-emulating oracle network: cosine >= 0.999.  The largest deviation is NOT held to 2e-2
+    here: two implementations of the same bf16 arithmetic differ in accumulation order, operands on a rounding boundary flip,
+    and this net's input gradient amplifies that (tools/check_bwd_bf16.py: the composed fp32 backward sits at the same 3.8e-2
+    relative L2 from the oracle as the fused one); the bound that holds by construction is the distance between the oracle's own
+    fp32 and bf16 gradients, and that is what is asserted."""
+    from oracle import diffwave_oracle as O
+    from audiopure_amd.diffusion_models._grad import EpsGrad
+    cfg = synth.mini_wavenet_config(256, 6, 12)
+    net, sd = _net(cfg, dev, seed=6)
+    net.set_precision("bf16")
+    w = O.fold_state_dict(sd)
+    B, L, step = 2, 1500, 3.0
+    x = torch.from_numpy(synth.waveforms(B, L, seed=11))
+    v = torch.from_numpy(synth.uniform(f"v{L}", (B, 1, L), 1, -1.0, 1.0))
+    refs = {}
+    for bf in (True, False):
+        xr = x.clone().requires_grad_(True)
+        eps_ref = O.eps_net(w, cfg, xr, torch.full((B, 1), step), bf16_operands=bf)
+        (refs[bf],) = torch.autograd.grad(eps_ref, xr, v)
+    eg = EpsGrad(net)
+    eps, saved = eg.forward_save(x.to(dev), step)
+    assert saved[3] is None                                      # bf16 mode keeps layer inputs only
+    g = eg.backward(saved, v.to(dev)).cpu()
+    eg.fused_bf16 = False
+    g_fp32 = eg.backward(saved, v.to(dev)).cpu()                 # same layer inputs, fp32 GEMMs
+    assert _cos(g, g_fp32) >= 0.9999 and rel_err(g.numpy(), g_fp32.numpy()) <= 2e-2, (_cos(g, g_fp32), rel_err(g.numpy(), g_fp32.numpy()))
+    l2 = lambda a, b: float((a - b).norm() / b.norm())
+    assert _cos(g, refs[True]) >= 0.999, _cos(g, refs[True])
+    assert l2(g, refs[True]) <= l2(refs[False], refs[True]), (l2(g, refs[True]), l2(refs[False], refs[True]))
