@@ -6,10 +6,15 @@
 //   K1  resblock_bwd_gate_bf16_kernel:  y = DilConv_d(bf16(h + part_t)) + b1   (recomputed: the forward's GEMM1)
 //                                       dg = [sqrt(1/2) W_res; W_skip]^T [dh'; dskip]
 //                                       dy = gate'(y) . dg   -> bf16 image [clip][sample][2C] (1 KB per sample, channels contiguous)
+//                                       (128-sample tiles, 8 waves; the y accumulators turn into packed fp16 gate factors before dg is accumulated)
 //   K2  resblock_bwd_conv_bf16_kernel:  dh = sqrt(1/2) dh' + DilConv_d^T(dy)   (direct three-tap form: flops are not what bounds bf16)
 // v_mfma_f32_32x32x16_bf16; B operands staged through LDS as [column][k] bf16 images with conflict-free 16-byte fragment reads, weights as
-// bf16 A fragments (8 k per lane) streamed L2 -> registers.  K2's staging is pure data movement: a (sample, tap) operand is a contiguous
-// 256-byte run of the dy image.  Built for res = skip = 256 channels.
+// bf16 A fragments (8 k per lane) streamed L2 -> registers through a ring three k-steps deep.  K2's staging is pure data movement: a
+// (sample, tap) operand is a contiguous 256-byte run of the dy image.  Built for res = skip = 256 channels.
+// Where the time goes at the white-box shape (B = 10: K1 0.30 ms, K2 0.19 ms per layer; MFMA pipes 26 % / 32 % busy, tools/time_bwd_bf16.py,
+// docs/HISTORY.md H): every tile re-reads its weight fragments (1 MB / 0.8 MB) through the CU's vector-memory path beside its activations.
+#include <type_traits>
+
 #include "ap_common.h"
 
 namespace ap {
@@ -19,12 +24,13 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int QC_ = 256;                  // res = skip channels
 constexpr int XSB_ = 96 + 8;              // bf16 per column row of K1's X chunk image (3 taps x 32 channels; 208-byte rows)
-constexpr int ZSB_ = 64 + 8;              // bf16 per column row of K1's Z chunk image (64 rows of [dh'; dskip]; 144-byte rows)
+constexpr int ZSB2_ = 128 + 8;            // bf16 per column row of K1's Z chunk image (128 rows of [dh'; dskip]; 272-byte rows)
 constexpr int DSB_ = 2 * QC_ + 8;         // bf16 per column row of K1's dy tile (520: 1040-byte rows)
 constexpr int YSB_ = 128 + 8;             // bf16 per column row of K2's chunk image (one tap x 128 channels; 272-byte rows)
 constexpr unsigned FRB_ = 64 * 16;        // bytes of one row tile's fragment of a k-step (64 lanes x 8 bf16)
@@ -37,31 +43,31 @@ __device__ __forceinline__ bf16x8 cvt8(const float (&v)[8]) {
 }  // namespace
 
 // ---- weight images (bf16, RNE) -----------------------------------------------------------------------------------------------
-// K1, y:  [wave 4][chunk 8][k-step 6][row tile 4][lane 64][8]; k-step ks of chunk ch: tap ks / 2, channel 32 ch + 16 (ks & 1) + 8 hh + jj;
-//         row tile rt: (rt & 1) C + 64 wave + 32 (rt >> 1) + i  (even = tanh rows, odd = sigmoid rows of the wave's 64 gate channels)
+// K1, y:  [wave 8][chunk 8][k-step 6][row tile 2][lane 64][8]; k-step ks of chunk ch: tap ks / 2, channel 32 ch + 16 (ks & 1) + 8 hh + jj;
+//         row tile rt: rt C + 32 wave + i  (0 = tanh rows, 1 = sigmoid rows of the wave's 32 gate channels)
 __global__ void pack_bw_w1y_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out) {
   constexpr int C = QC_;
   const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 4u * 8 * 6 * 4 * 64 * 8) return;
-  const int jj = idx & 7, lane = (idx >> 3) & 63, rt = (idx >> 9) & 3;
-  unsigned rest = idx >> 11;
+  if (idx >= 8u * 8 * 6 * 2 * 64 * 8) return;
+  const int jj = idx & 7, lane = (idx >> 3) & 63, rt = (idx >> 9) & 1;
+  unsigned rest = idx >> 10;
   const int ks = rest % 6; rest /= 6;
   const int ch = rest & 7, w = rest >> 3;
   const int i = lane & 31, hh = lane >> 5;
   const int tap = ks >> 1, c = 32 * ch + 16 * (ks & 1) + 8 * hh + jj;
-  const int o = (rt & 1) * C + 64 * w + 32 * (rt >> 1) + i;
+  const int o = rt * C + 32 * w + i;
   out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + tap];
 }
-// K1, dg: [wave 4][chunk 8][k-step 4][row tile 2][lane 64][8]; k = 64 chunk + 16 ks + 8 hh + jj over [res output (256); skip output (256)];
-//         row c = 64 wave + 32 rt + i; value W2[k][c], the res half times sqrt(1/2)
+// K1, dg: [wave 8][k-step 32][lane 64][8]; k = 16 ks + 8 hh + jj over [res output (256); skip output (256)];
+//         row c = 32 wave + i; value W2[k][c], the res half times sqrt(1/2)
 __global__ void pack_bw_w2t_kernel(const float *__restrict__ w2f, __bf16 *__restrict__ out) {
   constexpr int C = QC_;
   const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 4u * 8 * 4 * 2 * 64 * 8) return;
-  const int jj = idx & 7, lane = (idx >> 3) & 63, rt = (idx >> 9) & 1, ks = (idx >> 10) & 3, ch = (idx >> 12) & 7, w = idx >> 15;
+  if (idx >= 8u * 32 * 64 * 8) return;
+  const int jj = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 31, w = idx >> 14;
   const int i = lane & 31, hh = lane >> 5;
-  const int k = 64 * ch + 16 * ks + 8 * hh + jj;
-  const int c = 64 * w + 32 * rt + i;
+  const int k = 16 * ks + 8 * hh + jj;
+  const int c = 32 * w + i;
   const float v = w2f[(size_t)k * C + c];
   out[idx] = (__bf16)(k < C ? (float)((double)v * 0.70710678118654752440) : v);
 }
@@ -80,7 +86,7 @@ __global__ void pack_bw_w1b_kernel(const float *__restrict__ w1f, __bf16 *__rest
   out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + (2 - tp)];
 }
 
-constexpr size_t BW_W1Y_ = (size_t)4 * 8 * 6 * 4 * 64 * 8, BW_W2T_ = (size_t)4 * 8 * 4 * 2 * 64 * 8, BW_W1B_ = (size_t)4 * 12 * 8 * 2 * 64 * 8;
+constexpr size_t BW_W1Y_ = (size_t)8 * 8 * 6 * 2 * 64 * 8, BW_W2T_ = (size_t)8 * 32 * 64 * 8, BW_W1B_ = (size_t)4 * 12 * 8 * 2 * 64 * 8;
 
 static int launch_pack_bwd_bf16(ap_ctx *ctx, hipStream_t st) {
   const size_t n1f = (size_t)2 * QC_ * QC_ * 3, n2 = (size_t)2 * QC_ * QC_;
@@ -96,22 +102,26 @@ static int launch_pack_bwd_bf16(ap_ctx *ctx, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// K1: one workgroup = one (clip, 64-sample tile); 4 waves, wave w = gate channels [64 w, 64 w + 64): 128 y rows + 64 dg rows x 64 columns
+// K1: one workgroup = one (clip, 128-sample tile); 8 waves (two per SIMD, <= 256 registers each), wave w = gate channels [32 w, 32 w + 32):
+// 64 y rows, then 32 dg rows, x 128 columns.  The y accumulators do not live to the end: after GEMM 1 they become the gate's two
+// derivative factors, packed as an fp16 pair per (channel, sample) (|factor| <= 1, 11 significant bits: four times finer than the bf16
+// rounding dy gets anyway), which frees the registers GEMM 2 accumulates dg in.  Why 128 columns: a tile re-reads its weight fragments
+// (1 MB) from L2, and the per-CU L2 delivery rate is what bounds the 64-column form.
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void resblock_bwd_gate_bf16_kernel(
+__global__ __launch_bounds__(512) void resblock_bwd_gate_bf16_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, const float *__restrict__ dh, const float *__restrict__ dskip,
     __bf16 *__restrict__ dy, const __bf16 *__restrict__ w1y, const float *__restrict__ b1, const __bf16 *__restrict__ w2t, int L, int d,
     int ntiles) {
   constexpr int C = QC_;
-  constexpr int XB = 64 * XSB_, ZB = 64 * ZSB_;                    // bf16 elements per buffer
-  constexpr int STAGE = 2 * XB;                                    // the Z buffers alias the X ring (phase 2 starts behind a barrier)
-  __shared__ __attribute__((aligned(16))) __bf16 lds[STAGE + 64 * DSB_];   // 26.6 KB + 66.6 KB
-  static_assert(2 * ZB <= STAGE, "Z ring inside the X ring");
+  constexpr int NT = 128;
+  constexpr int XB = NT * XSB_, ZB = NT * ZSB2_;                   // bf16 elements per ring buffer
+  __shared__ __attribute__((aligned(16))) __bf16 lds[NT * DSB_];   // 133 KB: the dy tile of the epilogue; the X ring, then the Z ring, alias its start
+  static_assert(2 * XB <= NT * DSB_ && 2 * ZB <= NT * DSB_, "rings inside the dy tile");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ntiles));
-  const int t0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % ntiles) * 64);
+  const int t0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % ntiles) * NT);
   auto uni_rsrc = [&](const void *base, unsigned bytes) {
     const uint64_t hb = (uint64_t)base;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
@@ -121,13 +131,13 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_gate_bf16_kernel(
   const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
   const __amdgpu_buffer_rsrc_t hrs = uni_rsrc(hin + (size_t)b * C * L, clip_bytes);
   const float *dh_b = dh + (size_t)b * C * L, *ds_b = dskip + (size_t)b * C * L;
-  const __amdgpu_buffer_rsrc_t w1rs = uni_rsrc(reinterpret_cast<const char *>(w1y) + (size_t)wave * (8 * 6 * 4 * FRB_), 8 * 6 * 4 * FRB_);
-  const __amdgpu_buffer_rsrc_t w2rs = uni_rsrc(reinterpret_cast<const char *>(w2t) + (size_t)wave * (8 * 4 * 2 * FRB_), 8 * 4 * 2 * FRB_);
+  const __amdgpu_buffer_rsrc_t w1rs = uni_rsrc(reinterpret_cast<const char *>(w1y) + (size_t)wave * (8 * 6 * 2 * FRB_), 8 * 6 * 2 * FRB_);
+  const __amdgpu_buffer_rsrc_t w2rs = uni_rsrc(reinterpret_cast<const char *>(w2t) + (size_t)wave * (4 * 8 * FRB_), 4 * 8 * FRB_);
   const __amdgpu_buffer_rsrc_t ptrs = uni_rsrc(pt, C * 4u);
   const unsigned lane16 = (unsigned)lane * 16u;
 
   // ---- phase 1: y = DilConv(bf16(h + part_t)); chunk = 32 channels x 3 taps = 6 k-steps.  Staging thread = (column sj, channel octet sq)
-  const int sj = tid & 63, sq = tid >> 6;
+  const int sj = tid & 127, sq = tid >> 7;
   unsigned xv[3];
 #pragma unroll
   for (int tap = 0; tap < 3; tap++) {
@@ -155,133 +165,146 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_gate_bf16_kernel(
       *reinterpret_cast<bf16x8 *>(dst + sj * XSB_ + 32 * tap + 8 * sq) = cvt8(u);
     }
   };
-  f32x16 accy[4][2];
-#pragma unroll
-  for (int rt = 0; rt < 4; rt++)
-#pragma unroll
-    for (int ct = 0; ct < 2; ct++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) accy[rt][ct][r] = 0.f;
-  auto load_a1 = [&](bf16x8(&a)[4], int step) {                  // weight fragments of k-step `step` (0 .. 47), one step ahead of their MFMAs
-#pragma unroll
-    for (int rt = 0; rt < 4; rt++)
-      a[rt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane16 + rt * FRB_, step * 4 * FRB_, 0));
-  };
-  bf16x8 a1[2][4];
-  load_a1(a1[0], 0);
-  issue_x(0);
-  store_x(lds);
-  __syncthreads();
-#pragma unroll 1
-  for (int ch = 0; ch < 8; ch++) {
-    const __bf16 *xb = lds + (ch & 1) * XB + j * XSB_ + 8 * hh;
-    issue_x(ch + 1 < 8 ? ch + 1 : ch);
-    bf16x8 bq[2][2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ct++) bq[0][ct] = *reinterpret_cast<const bf16x8 *>(xb + 32 * ct * XSB_);
-#pragma unroll
-    for (int ks = 0; ks < 6; ks++) {
-      const int nx = ch * 6 + ks + 1;
-      load_a1(a1[(ks + 1) & 1], nx < 48 ? nx : 47);
-      if (ks + 1 < 6) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) bq[(ks + 1) & 1][ct] = *reinterpret_cast<const bf16x8 *>(xb + 32 * ct * XSB_ + 16 * (ks + 1));
-      }
-#pragma unroll
-      for (int rt = 0; rt < 4; rt++)
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) accy[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[ks & 1][rt], bq[ks & 1][ct], accy[rt][ct], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    store_x(lds + ((ch + 1) & 1) * XB);                           // (the last chunk stores its own re-requested copy into the idle buffer)
-    __syncthreads();
-  }
-
-  // ---- phase 2: dg = W2^T [dh'; dskip]; chunk = 64 rows of the concatenation = 4 k-steps.  Staging thread = (column sj, 16 rows 16 sq ..)
+  // phase 2's operand: chunk = 128 rows of [dh'; dskip] = 8 k-steps; staging thread = (column sj, 32 rows 32 sq ..)
   const int ts = t0 + sj;
-  const unsigned zv = ts < L ? ((unsigned)ts + (unsigned)(16 * sq) * (unsigned)L) * 4u : 0x80000000u;
-  float zr[16];
-  auto issue_z = [&](int kc) {                                   // chunks 0..3: dh' rows, 4..7: dskip rows
-    const __amdgpu_buffer_rsrc_t rs = uni_rsrc(kc < 4 ? dh_b : ds_b, clip_bytes);
+  const unsigned zv = ts < L ? ((unsigned)ts + (unsigned)(32 * sq) * (unsigned)L) * 4u : 0x80000000u;
+  float zr[32];
+  auto issue_z = [&](int kc) {                                   // chunks 0, 1: dh' rows, 2, 3: dskip rows
+    const __amdgpu_buffer_rsrc_t rs = uni_rsrc(kc < 2 ? dh_b : ds_b, clip_bytes);
 #pragma unroll
-    for (int i = 0; i < 16; i++) zr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zv, ((kc & 3) * 64 + i) * L * 4, 0));
+    for (int i = 0; i < 32; i++) zr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zv, ((kc & 1) * 128 + i) * L * 4, 0));
   };
   auto store_z = [&](__bf16 *dst) {
-    float lo[8], hi[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { lo[i] = zr[i]; hi[i] = zr[8 + i]; }
-    *reinterpret_cast<bf16x8 *>(dst + sj * ZSB_ + 16 * sq) = cvt8(lo);
-    *reinterpret_cast<bf16x8 *>(dst + sj * ZSB_ + 16 * sq + 8) = cvt8(hi);
+    for (int o = 0; o < 4; o++) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = zr[8 * o + i];
+      *reinterpret_cast<bf16x8 *>(dst + sj * ZSB2_ + 32 * sq + 8 * o) = cvt8(v);
+    }
   };
-  f32x16 accg[2][2];
+
+  f32x16 accy[2][4];                                             // start from the conv's bias: rows rowoff(4 q .. 4 q + 3, hh) are channels 32 wave + 8 q + 4 hh ..
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++)
+    for (int q = 0; q < 4; q++) {
+      const f32x4 bv = *reinterpret_cast<const f32x4 *>(b1 + rt * C + 32 * wave + 8 * q + 4 * hh);
 #pragma unroll
-      for (int r = 0; r < 16; r++) accg[rt][ct][r] = 0.f;
-  auto load_a2 = [&](bf16x8(&a)[2], int step) {                  // k-step `step` of 32
+      for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) accy[rt][ct][4 * q + e] = bv[e];
+    }
+  auto load_a1 = [&](bf16x8(&a)[2], int step) {                  // weight fragments of k-step `step` (0 .. 47), one step ahead of their MFMAs
 #pragma unroll
     for (int rt = 0; rt < 2; rt++)
-      a[rt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane16 + rt * FRB_, step * 2 * FRB_, 0));
+      a[rt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w1rs, lane16 + rt * FRB_, step * 2 * FRB_, 0));
   };
-  bf16x8 a2[2][2];
-  load_a2(a2[0], 0);
-  issue_z(0);
-  store_z(lds);
+  // The weight fragments ride a ring of four k-steps, requested three steps (~1 500 cycles at two waves per SIMD) before their MFMAs: vmcnt
+  // retires in order, so the first wait on a fragment requested AFTER a chunk's activation loads also waits for those -- the ring's depth is
+  // the time the activation loads get before anything stalls on them (at depth one every k-step waited out an L2 round trip).
+  bf16x8 a1[4][2];
+  load_a1(a1[0], 0);
+  load_a1(a1[1], 1);
+  load_a1(a1[2], 2);
+  issue_x(0);
+  store_x(lds);
   __syncthreads();
-#pragma unroll 1
-  for (int kc = 0; kc < 8; kc++) {
-    const __bf16 *zb = lds + (kc & 1) * ZB + j * ZSB_ + 8 * hh;
-    issue_z(kc + 1 < 8 ? kc + 1 : kc);
-    bf16x8 bq[2][2];
+  auto chunk1 = [&](auto P, int ch) {                            // P = ch & 1: the ring slot of k-step ks is (2 P + ks) & 3
+    constexpr int pb = decltype(P)::value;
+    const __bf16 *xb = lds + pb * XB + j * XSB_ + 8 * hh;
+    if (ch + 1 < 8) issue_x(ch + 1);
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) bq[0][ct] = *reinterpret_cast<const bf16x8 *>(zb + 32 * ct * ZSB_);
+    for (int ks = 0; ks < 6; ks++) {
+      const int slot = (2 * pb + ks) & 3;
+      const int nx = ch * 6 + ks + 3;
+      load_a1(a1[(slot + 3) & 3], nx < 48 ? nx : 47);
+      bf16x8 bq[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const int nx = kc * 4 + ks + 1;
-      load_a2(a2[(ks + 1) & 1], nx < 32 ? nx : 31);
-      if (ks + 1 < 4) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ct++) bq[(ks + 1) & 1][ct] = *reinterpret_cast<const bf16x8 *>(zb + 32 * ct * ZSB_ + 16 * (ks + 1));
-      }
+      for (int ct = 0; ct < 4; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(xb + 32 * ct * XSB_ + 16 * ks);
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) accg[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 1][rt], bq[ks & 1][ct], accg[rt][ct], 0, 0, 0);
+        for (int ct = 0; ct < 4; ct++) accy[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[slot][rt], bq[ct], accy[rt][ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    store_z(lds + ((kc + 1) & 1) * ZB);
+    if (ch + 1 < 8) store_x(lds + (pb ^ 1) * XB);
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int ch = 0; ch < 8; ch += 2) {
+    chunk1(std::integral_constant<int, 0>{}, ch);
+    chunk1(std::integral_constant<int, 1>{}, ch + 1);
+  }
+  issue_z(0);                                                    // in flight behind the gate arithmetic
+
+  // ---- the gate's derivative factors: dy_tanh = dg . sg (1 - th^2), dy_sig = dg . th sg (1 - sg); packed (fp16, fp16)
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  f16x2 fac[4][16];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const float at = fminf(fmaxf(accy[0][ct][r], -15.0f), 15.0f), as = fmaxf(accy[1][ct][r], -80.0f);
+      const float E = exp_acc(2.0f * at), F = exp_acc(-as);
+      const float R = __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
+      const float th = (E - 1.0f) * (1.0f + F) * R, sg = (E + 1.0f) * R;
+      const f32x2 f = {sg * (1.0f - th * th), th * sg * (1.0f - sg)};
+      fac[ct][r] = __builtin_convertvector(f, f16x2);
+    }
+
+  // ---- phase 2: dg = W2^T [dh'; dskip]
+  f32x16 accg[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) accg[ct][r] = 0.f;
+  auto load_a2 = [&](int step) {                                 // k-step `step` of 32
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane16, step * FRB_, 0));
+  };
+  bf16x8 a2[4];
+  a2[0] = load_a2(0);
+  a2[1] = load_a2(1);
+  a2[2] = load_a2(2);
+  store_z(lds);
+  __syncthreads();
+#pragma unroll 1
+  for (int kc = 0; kc < 4; kc++) {
+    const __bf16 *zb = lds + (kc & 1) * ZB + j * ZSB2_ + 8 * hh;
+    if (kc + 1 < 4) issue_z(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {                               // (B fragments read in place: the SIMD's other wave covers the LDS latency,
+      const int nx = kc * 8 + ks + 3;                              //  and a second set would not fit beside the packed factors)
+      a2[(ks + 3) & 3] = load_a2(nx < 32 ? nx : 31);
+      bf16x8 bq[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(zb + 32 * ct * ZSB2_ + 16 * ks);
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) accg[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 3], bq[ct], accg[ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kc + 1 < 4) store_z(lds + ((kc + 1) & 1) * ZB);
     __syncthreads();
   }
 
-  // ---- epilogue: dy = gate'(y) . dg into the tile image [column][2C] (bf16), then out as whole 1 KB sample rows
-  __bf16 *dyt = lds + STAGE;
+  // ---- epilogue: dy = factor . dg into the tile image [column][2C] (bf16), then out as whole 1 KB sample rows
 #pragma unroll
-  for (int p = 0; p < 2; p++)
+  for (int ct = 0; ct < 4; ct++)
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++)
+    for (int q = 0; q < 4; q++) {
+      const int c0 = 32 * wave + 8 * q + 4 * hh;
+      float vt[4], vs[4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int c0 = 64 * wave + 32 * p + 8 * q + 4 * hh;         // rows rowoff(4 q .. 4 q + 3, hh) are consecutive channels
-        const f32x4 bt = *reinterpret_cast<const f32x4 *>(b1 + c0), bs = *reinterpret_cast<const f32x4 *>(b1 + C + c0);
-        float vt[4], vs[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-          const int r = 4 * q + e;
-          const float at = fminf(fmaxf(accy[2 * p][ct][r] + bt[e], -15.0f), 15.0f), as = fmaxf(accy[2 * p + 1][ct][r] + bs[e], -80.0f);
-          const float E = exp_acc(2.0f * at), F = exp_acc(-as);
-          const float R = __builtin_amdgcn_rcpf((E + 1.0f) * (1.0f + F));
-          const float th = (E - 1.0f) * (1.0f + F) * R, sg = (E + 1.0f) * R;
-          const float g = accg[p][ct][r];
-          vt[e] = g * sg * (1.0f - th * th);
-          vs[e] = g * th * sg * (1.0f - sg);
-        }
-        const f32x4 ft = {vt[0], vt[1], vt[2], vt[3]}, fs = {vs[0], vs[1], vs[2], vs[3]};
-        __bf16 *row = dyt + (32 * ct + j) * DSB_;
-        *reinterpret_cast<bf16x4 *>(row + c0) = __builtin_convertvector(ft, bf16x4);
-        *reinterpret_cast<bf16x4 *>(row + C + c0) = __builtin_convertvector(fs, bf16x4);
+      for (int e = 0; e < 4; e++) {
+        const f32x2 f = __builtin_convertvector(fac[ct][4 * q + e], f32x2);
+        vt[e] = accg[ct][4 * q + e] * f[0];
+        vs[e] = accg[ct][4 * q + e] * f[1];
       }
+      const f32x4 ft = {vt[0], vt[1], vt[2], vt[3]}, fs = {vs[0], vs[1], vs[2], vs[3]};
+      __bf16 *row = lds + (32 * ct + j) * DSB_;
+      *reinterpret_cast<bf16x4 *>(row + c0) = __builtin_convertvector(ft, bf16x4);
+      *reinterpret_cast<bf16x4 *>(row + C + c0) = __builtin_convertvector(fs, bf16x4);
+    }
   __syncthreads();
   {
     const __amdgpu_buffer_rsrc_t ors = uni_rsrc(dy + (size_t)b * L * 2 * C, (unsigned)L * 2u * C * 2u);
@@ -290,24 +313,27 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_gate_bf16_kernel(
     const unsigned off = t < L ? (unsigned)t * 1024u + (unsigned)part * 256u : 0x80000000u;
 #pragma unroll
     for (int i = 0; i < 16; i++)
-      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4b *>(dyt + col * DSB_ + 128 * part + 8 * i), ors, off + 16u * i, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4b *>(lds + col * DSB_ + 128 * part + 8 * i), ors, off + 16u * i, 0, 0);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// K2: one workgroup = one (clip, 64-sample tile); 4 waves x (64 rows x 64 columns); two workgroups per CU
+// K2: one workgroup = one (clip, 64-sample tile); 4 waves x (64 rows x 64 columns), 132 registers: three workgroups per CU.
+// (Measured and not kept, docs/HISTORY.md H: 128-column tiles at two workgroups per CU and 64-column tiles at four per CU -- both 3-7 % slower.)
 // ---------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __bf16 *__restrict__ dy, const float *__restrict__ dhp,
                                                                         float *__restrict__ dhin, const __bf16 *__restrict__ w1b,
                                                                         int L, int d, int ntiles) {
   constexpr int C = QC_;
-  constexpr int YB = 64 * YSB_;
+  constexpr int CT = 2, NT = 32 * CT;                             // column tiles of 32, columns of a tile
+  constexpr int YB = NT * YSB_;
+  constexpr int PPT = 2 * CT, TPC = 16 / PPT;                     // 16-byte pieces per staging thread, threads per column
   __shared__ __attribute__((aligned(16))) __bf16 lds[2 * YB];     // 34.8 KB
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
   const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ntiles));
-  const int t0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % ntiles) * 64);
+  const int t0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % ntiles) * NT);
   auto uni_rsrc = [&](const void *base, unsigned bytes) {
     const uint64_t hb = (uint64_t)base;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
@@ -317,29 +343,29 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
   const __amdgpu_buffer_rsrc_t yrs = uni_rsrc(dy + (size_t)b * L * 2 * C, (unsigned)L * 2u * C * 2u);
   const __amdgpu_buffer_rsrc_t wrs = uni_rsrc(reinterpret_cast<const char *>(w1b) + (size_t)wave * (12 * 8 * 2 * FRB_), 12 * 8 * 2 * FRB_);
   const unsigned lane16 = (unsigned)lane * 16u;
-  // staging: thread = (column tid >> 2, quarter tid & 3) of a chunk's 256-byte (column, tap) run: 4 x 16 B
-  const int scol = tid >> 2, spart = tid & 3;
+  // staging: thread = (column tid / TPC, part tid % TPC) of a chunk's 256-byte (column, tap) run: PPT x 16 B
+  const int scol = tid / TPC, spart = tid % TPC;
   unsigned yv[3];
 #pragma unroll
   for (int tp = 0; tp < 3; tp++) {
     const int t = t0 + scol + (tp - 1) * d;
-    yv[tp] = (t >= 0 && t < L) ? (unsigned)t * 1024u + (unsigned)spart * 64u : 0x80000000u;    // outside the clip: zeros (WaveNet.py:26-27)
+    yv[tp] = (t >= 0 && t < L) ? (unsigned)t * 1024u + (unsigned)spart * (16u * PPT) : 0x80000000u;    // outside the clip: zeros (WaveNet.py:26-27)
   }
-  u32x4b yq[4];
+  u32x4b yq[PPT];
   auto issue_y = [&](int ch) {
     const unsigned v = (ch >> 2) == 0 ? yv[0] : (ch >> 2) == 1 ? yv[1] : yv[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) yq[i] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(yrs, v, (ch & 3) * 256 + 16 * i, 0));
+    for (int i = 0; i < PPT; i++) yq[i] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(yrs, v, (ch & 3) * 256 + 16 * i, 0));
   };
   auto store_y = [&](__bf16 *dst) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) *reinterpret_cast<u32x4b *>(dst + scol * YSB_ + 32 * spart + 8 * i) = yq[i];
+    for (int i = 0; i < PPT; i++) *reinterpret_cast<u32x4b *>(dst + scol * YSB_ + 8 * PPT * spart + 8 * i) = yq[i];
   };
-  f32x16 acc[2][2];
+  f32x16 acc[2][CT];
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++)
+    for (int ct = 0; ct < CT; ct++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[rt][ct][r] = 0.f;
   auto load_a = [&](bf16x8(&a)[2], int step) {                   // k-step `step` of 96
@@ -347,8 +373,10 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
     for (int rt = 0; rt < 2; rt++)
       a[rt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16 + rt * FRB_, step * 2 * FRB_, 0));
   };
-  bf16x8 aw[2][2];
+  bf16x8 aw[4][2];                                               // ring of four k-steps, requested three ahead (see K1)
   load_a(aw[0], 0);
+  load_a(aw[1], 1);
+  load_a(aw[2], 2);
   issue_y(0);
   store_y(lds);
   __syncthreads();
@@ -356,21 +384,23 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
   for (int ch = 0; ch < 12; ch++) {
     const __bf16 *yb = lds + (ch & 1) * YB + j * YSB_ + 8 * hh;
     issue_y(ch + 1 < 12 ? ch + 1 : ch);
-    bf16x8 bq[2][2];
+    constexpr int DB = 1;
+    bf16x8 bq[DB + 1][CT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) bq[0][ct] = *reinterpret_cast<const bf16x8 *>(yb + 32 * ct * YSB_);
+    for (int ct = 0; ct < CT; ct++) bq[0][ct] = *reinterpret_cast<const bf16x8 *>(yb + 32 * ct * YSB_);
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
-      const int nx = ch * 8 + ks + 1;
-      load_a(aw[(ks + 1) & 1], nx < 96 ? nx : 95);
-      if (ks + 1 < 8) {
+      const int nx = ch * 8 + ks + 3;
+      load_a(aw[(ks + 3) & 3], nx < 96 ? nx : 95);
+      if (DB ? ks + 1 < 8 : ks > 0) {
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) bq[(ks + 1) & 1][ct] = *reinterpret_cast<const bf16x8 *>(yb + 32 * ct * YSB_ + 16 * (ks + 1));
+        for (int ct = 0; ct < CT; ct++)
+          bq[(ks + 1) & DB][ct] = *reinterpret_cast<const bf16x8 *>(yb + 32 * ct * YSB_ + 16 * (ks + DB));
       }
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-        for (int ct = 0; ct < 2; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks & 1][rt], bq[ks & 1][ct], acc[rt][ct], 0, 0, 0);
+        for (int ct = 0; ct < CT; ct++) acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks & 3][rt], bq[ks & DB][ct], acc[rt][ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     store_y(lds + ((ch + 1) & 1) * YB);
@@ -384,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
 #pragma unroll
   for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
+    for (int ct = 0; ct < CT; ct++) {
       const int t = t0 + 32 * ct + j;
       const unsigned eo = t < L ? ((unsigned)(64 * wave + 32 * rt + 4 * hh) * (unsigned)L + (unsigned)t) * 4u : 0x80000000u;
       float rv[16];
@@ -416,9 +446,9 @@ int launch_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *hin, const flo
   }
   const __bf16 *p = (const __bf16 *)ctx->slab_bb + (size_t)layer * (BW_W1Y_ + BW_W2T_ + BW_W1B_);
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
-  const int nt = (L + 63) / 64;
-  resblock_bwd_gate_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>(hin, pt, dhp, dskip, (__bf16 *)dy, p, ctx->b1 + (size_t)layer * 2 * QC_,
-                                                                    p + BW_W1Y_, L, d, nt);
+  const int nt = (L + 63) / 64, nt4 = (L + 127) / 128;
+  resblock_bwd_gate_bf16_kernel<<<(unsigned)(B * nt4), 512, 0, st>>>(hin, pt, dhp, dskip, (__bf16 *)dy, p, ctx->b1 + (size_t)layer * 2 * QC_,
+                                                                     p + BW_W1Y_, L, d, nt4);
   resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W1Y_ + BW_W2T_, L, d, nt);
   AP_HIP(hipGetLastError());
   return 0;
