@@ -416,6 +416,20 @@ def test_convnet_backward_covers_cat_slices_and_pools(dev):
     assert d.max() < 2e-2 and np.median(d) < 1e-5, (d.max(), np.median(d))
 
 
+def _guarded(shape, dev, dtype=torch.float32, fill=5.0, guard=2048):
+    """A tensor inside guard bands of a sentinel: (buffer, view, check) -- check() asserts nothing was written outside the view."""
+    n = 1
+    for v in shape:
+        n *= v
+    buf = torch.full((n + 2 * guard,), 7.25, device=dev, dtype=dtype)
+    view = buf[guard:guard + n].view(*shape)
+    view.fill_(fill)
+
+    def check():
+        assert bool((buf[:guard] == 7.25).all()) and bool((buf[guard + n:] == 7.25).all()), "write outside the output buffer"
+    return buf, view, check
+
+
 @pytest.mark.parametrize("L,layer", [(1100, 0), (2048, 5), (1000, 11), (16000, 6), (130, 3), (77, 9), (5, 1), (129, 6), (4133, 7), (16000, 1),
                                      (1, 0), (64, 4), (4100, 10)])
 def test_fused_block_backward_matches_autograd_through_the_oracle(dev, L, layer):
@@ -454,11 +468,15 @@ def test_fused_block_backward_matches_autograd_through_the_oracle(dev, L, layer)
     assert torch.equal(hout, hout2) and torch.equal(sk, sk2)
     assert rel_err(hout.cpu().numpy(), h_ref.detach().numpy()) < 5e-6
     assert rel_err(pre.cpu().numpy(), y_ref.numpy()) < 5e-6
-    dy = torch.empty_like(pre)
-    dh_in = torch.full_like(hd, 5.0)
+    _, dy, dy_ok = _guarded(pre.shape, dev)                      # both outputs inside guard bands that must stay untouched
+    _, dh_in, dh_ok = _guarded(hd.shape, dev)
     ghd, gsd = gh.to(dev), gs.to(dev)                            # (held: a temporary's block would be reused by the next .to())
     N.check(lib.ap_resblock_bwd(eng.ctx, layer, N.ptr(ghd), N.ptr(gsd), N.ptr(pre), N.ptr(dy), N.ptr(dh_in), B, L, N.stream()))
     assert rel_err(dh_in.cpu().numpy(), g_ref.numpy()) < 1e-5
+    dy_ok(); dh_ok()
+    first = dh_in.clone()
+    N.check(lib.ap_resblock_bwd(eng.ctx, layer, N.ptr(ghd), N.ptr(gsd), N.ptr(pre), N.ptr(dy), N.ptr(dh_in), B, L, N.stream()))
+    assert torch.equal(first, dh_in)                             # run to run bit-identical
 
 
 def _cos(a, b):
@@ -466,7 +484,8 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("L,layer", [(1100, 0), (2048, 5), (1000, 11), (16000, 6), (130, 3), (77, 9), (64, 4), (4100, 10), (16000, 1)])
+@pytest.mark.parametrize("L,layer", [(1100, 0), (2048, 5), (1000, 11), (16000, 6), (130, 3), (77, 9), (64, 4), (4100, 10), (16000, 1),
+                                     (5, 1), (1, 0), (129, 6), (4133, 7), (127, 2), (128, 8)])
 def test_bf16_block_backward_matches_autograd_through_the_bf16_oracle(dev, L, layer):
     """ap_resblock_bwd_bf16 (bf16 MFMA operands, the dilated conv recomputed from the layer input) against
     torch autograd through the bf16-emulating oracle block (both forward GEMMs see bf16-rounded operands; its backward multiplies
@@ -492,13 +511,16 @@ def test_bf16_block_backward_matches_autograd_through_the_bf16_oracle(dev, L, la
     with torch.no_grad():
         part_t = torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
     hd, ptd, ghd, gsd = h.to(dev), part_t.to(dev).contiguous(), gh.to(dev), gs.to(dev)
-    dy = torch.zeros((B, L, 2 * C_), device=dev, dtype=torch.bfloat16)
-    dh_in = torch.full_like(hd, 5.0)
+    _, dy, dy_ok = _guarded((B, L, 2 * C_), dev, torch.bfloat16, 0.0)   # both outputs inside guard bands that must stay untouched
+    _, dh_in, dh_ok = _guarded(hd.shape, dev)
     N.check(lib.ap_resblock_bwd_bf16(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ghd), N.ptr(gsd), dy.data_ptr(), N.ptr(dh_in), B, L, N.stream()))
     got = dh_in.cpu()
     assert torch.isfinite(got).all()
     assert _cos(got, g_ref) >= 0.999, (_cos(got, g_ref),)
     assert rel_err(got.numpy(), g_ref.numpy()) <= 2e-2
+    dy_ok(); dh_ok()
+    N.check(lib.ap_resblock_bwd_bf16(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ghd), N.ptr(gsd), dy.data_ptr(), N.ptr(dh_in), B, L, N.stream()))
+    assert torch.equal(got, dh_in.cpu())                         # run to run bit-identical
 
 
 def test_bf16_eps_vjp_runs_on_the_bf16_backward_and_matches_the_bf16_oracle(dev):

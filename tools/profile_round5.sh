@@ -5,7 +5,7 @@
 #      WRITE_SIZE) of the SAME command; the direct-form kernel (f32d) the same way for comparison;
 #   3. timing-only ablations and the same-process A/Bs of the F(2,3) block (tools build);
 #   4. configs[4]: per conv shape, the A/B of the conv forms, the rocprofv3 --stats split of the whole step, PMC of one w3 layer;
-#   5. the white-box gradient step and its kernel split; 6. the adversarial-operand error table of the fp32-class modes.
+#   5. the white-box gradient step and its kernel split in fp32 and bf16 mode, SQ / traffic counters of the two bf16 backward kernels; 6. the adversarial-operand error table of the fp32-class modes.
 #   bash tools/profile_round5.sh [outdir under gpurun_out]        then: python tools/summarize_round5.py <outdir>
 set -u
 out=${1:-gpurun_out/r5}
@@ -26,5 +26,11 @@ bash "$repo/tools/pmc_kernel.sh" "$out/pmc_w3" conv2d_w3 -- "$repo/tools/run_con
 timeout 300 python3 "$repo/tools/bench_whitebox.py" 10 5 f32 2>&1 | grep -v amdgpu.ids > "$repo/$out/whitebox.txt"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/wb_stats" -o r -- python3 "$repo/tools/bench_whitebox.py" 10 5 f32 > "$repo/$out/wb_stats.log" 2>&1
 cp "$repo/$out"/wb_stats/*kernel_stats.csv "$repo/$out/whitebox_kernel_stats.csv" 2>/dev/null
+timeout 300 python3 "$repo/tools/bench_whitebox.py" 10 5 bf16 2>&1 | grep -v amdgpu.ids > "$repo/$out/whitebox_bf16.txt"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/wbb_stats" -o r -- python3 "$repo/tools/bench_whitebox.py" 10 5 bf16 > "$repo/$out/wbb_stats.log" 2>&1
+cp "$repo/$out"/wbb_stats/*kernel_stats.csv "$repo/$out/whitebox_bf16_kernel_stats.csv" 2>/dev/null
+bash "$repo/tools/pmc_kernel.sh" "$out/pmc_bwdb_gate" resblock_bwd_gate_bf16 -- "$repo/tools/time_bwd_bf16.py" 10 > "$repo/$out/pmc_bwdb_gate.log" 2>&1
+bash "$repo/tools/pmc_kernel.sh" "$out/pmc_bwdb_conv" resblock_bwd_conv_bf16 -- "$repo/tools/time_bwd_bf16.py" 10 > "$repo/$out/pmc_bwdb_conv.log" 2>&1
+timeout 200 python3 "$repo/tools/check_bwd_bf16.py" 2>&1 | grep -v amdgpu.ids > "$repo/$out/bwd_bf16_deviation.txt"
 timeout 300 python3 "$repo/tools/adversarial_error.py" f32d f32 f32s 2>&1 | grep -v amdgpu.ids > "$repo/$out/adversarial_error.txt"
 ls "$repo/$out"

@@ -28,6 +28,9 @@ for a, b in (("bench.json", "r5_bench.json"), ("bench_torchrun_n1.json", "r5_ben
              ("f32w_ablation.txt", "r5_f32w_ablation.txt"), ("f32w_ab.txt", "r5_f32w_ab.txt"), ("conv_w3_ab.txt", "r5_conv_w3_ab.txt"),
              ("cfg4_conv_by_shape.txt", "r5_cfg4_conv_by_shape.txt"), ("cfg4_kernel_stats.csv", "r5_cfg4_kernel_stats.csv"),
              ("whitebox.txt", "r5_whitebox_gradient_step.txt"), ("whitebox_kernel_stats.csv", "r5_whitebox_kernel_stats.csv"),
+             ("whitebox_bf16.txt", "r5_whitebox_bf16_gradient_step.txt"), ("whitebox_bf16_kernel_stats.csv", "r5_whitebox_bf16_kernel_stats.csv"),
+             ("pmc_bwdb_gate/summary.json", "r5_whitebox_bf16_gate_kernel_pmc.json"), ("pmc_bwdb_conv/summary.json", "r5_whitebox_bf16_conv_kernel_pmc.json"),
+             ("bwd_bf16_deviation.txt", "r5_whitebox_bf16_deviation.txt"),
              ("adversarial_error.txt", "r5_fp32_class_adversarial_error_rerun.txt")):
     cp(a, b)
 for key, kern, flops in (("f32w", "resblock_f32w_kernel (F(2,3) form)", FLOP_EXEC), ("f32d", "resblock_f32_kernel<256,64> (direct form)", FLOP_DIRECT)):
