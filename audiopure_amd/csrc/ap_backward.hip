@@ -39,17 +39,34 @@ __global__ void relu_outer_bwd_kernel(const float *__restrict__ r, const float *
 }
 
 // init_conv backward (WaveNet.py:147,168): h0 = relu(w0[c] x + b0[c])  ->  dx[b][t] = sum_c [h0 > 0] w0[c] dh0[b][c][t]
-__global__ void init_conv_bwd_kernel(const float *__restrict__ h0, const float *__restrict__ w0,
-                                     const float *__restrict__ dh0, float *__restrict__ dx, int C, int L) {
+// Workgroup = 64 samples x 4 channel quarters; eight channels' loads in flight per thread, the quarters summed through LDS in a fixed
+// order (one thread walking all C channels with a dependent load pair per step ran at 0.7 TB/s: 0.23 ms at B = 10).
+__global__ __launch_bounds__(256) void init_conv_bwd_kernel(const float *__restrict__ h0, const float *__restrict__ w0,
+                                                            const float *__restrict__ dh0, float *__restrict__ dx, int C, int L) {
+  __shared__ float part[4][64];
   const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= L) return;
+  const int tl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + tl;
+  const int cq = (C + 3) / 4, c0 = q * cq, c1 = min(C, c0 + cq);
   float s = 0.f;
-  for (int c = 0; c < C; c++) {
-    const size_t i = ((size_t)b * C + c) * L + t;
-    if (h0[i] > 0.f) s = __builtin_fmaf(w0[c], dh0[i], s);
+  if (t < L) {
+    const size_t base = (size_t)b * C * L + t;
+    int c = c0;
+    for (; c + 8 <= c1; c += 8) {
+      float hv[8], dv[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) { hv[i] = h0[base + (size_t)(c + i) * L]; dv[i] = dh0[base + (size_t)(c + i) * L]; }
+#pragma unroll
+      for (int i = 0; i < 8; i++) s = hv[i] > 0.f ? __builtin_fmaf(w0[c + i], dv[i], s) : s;
+    }
+    for (; c < c1; c++) {
+      const float hv = h0[base + (size_t)c * L], dv = dh0[base + (size_t)c * L];
+      s = hv > 0.f ? __builtin_fmaf(w0[c], dv, s) : s;
+    }
   }
-  dx[(size_t)b * L + t] = s;
+  part[q][tl] = s;
+  __syncthreads();
+  if (q == 0 && t < L) dx[(size_t)b * L + t] = (part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]);
 }
 
 // ---- pieces of the input gradient of the lowered 2-D classifiers (audiopure_amd/convnet.py backward) ----
@@ -208,7 +225,7 @@ extern "C" int ap_relu_outer_bwd(const float *r, const float *w2, const float *d
 extern "C" int ap_init_conv_bwd(const float *h0, const float *w0, const float *dh0, float *dx, int B, int C, int L,
                                 void *stream) {
   if (!h0 || !w0 || !dh0 || !dx || B < 1 || C < 1 || L < 1) { set_error("ap_init_conv_bwd: bad argument"); return -22; }
-  dim3 grid((L + 255) / 256, B);
+  dim3 grid((L + 63) / 64, B);
   init_conv_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(h0, w0, dh0, dx, C, L);
   AP_HIP(hipGetLastError());
   return 0;
