@@ -128,7 +128,19 @@ class EpsGrad:
         skip = torch.empty((B, S_, L), device=dev)
         pre = torch.empty((NL, B, 2 * C_, L), device=dev) if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256) else None
         N.check(lib.ap_init_conv(eng.ctx, N.ptr(x), N.ptr(hs[0]), B, L, N.stream()), "ap_init_conv")
-        for n in range(NL):
+        G = int(eng.skip_group or 0) if getattr(eng, "_ds_ok", False) and self.net._precision == N.AP_PREC_BF16 else 0
+        if G > 0:
+            # bf16 mode, the deferred-skip form the chain's own forward runs (ap_resblock_fwd_gate + one ap_skip_gemm per group of G
+            # layers: same grouping, so eps equals ap_eps_fwd's bit for bit); the last layer's h' is not computed (nobody reads it)
+            gimg = torch.empty((min(G, NL), B, L, C_), device=dev, dtype=torch.bfloat16)
+            for n0 in range(0, NL, G):
+                nl = min(G, NL - n0)
+                for n in range(n0, n0 + nl):
+                    N.check(lib.ap_resblock_fwd_gate(eng.ctx, n, N.ptr(hs[n]), N.ptr(part[n * C_:(n + 1) * C_]),
+                                                     N.ptr(hs[n + 1]) if n + 1 < NL else None, gimg[n - n0].data_ptr(), B, L, N.stream()),
+                            "ap_resblock_fwd_gate")
+                N.check(lib.ap_skip_gemm(eng.ctx, n0, nl, gimg.data_ptr(), N.ptr(skip), 1 if n0 else 0, B, L, N.stream()), "ap_skip_gemm")
+        for n in range(NL if G == 0 else 0):
             pt = part[n * C_:(n + 1) * C_]
             if pre is not None:
                 N.check(lib.ap_resblock_fwd_save(eng.ctx, n, N.ptr(hs[n]), N.ptr(pt), N.ptr(hs[n + 1]), N.ptr(skip), N.ptr(pre[n]),

@@ -549,6 +549,7 @@ def test_bf16_eps_vjp_runs_on_the_bf16_backward_and_matches_the_bf16_oracle(dev)
     eg = EpsGrad(net)
     eps, saved = eg.forward_save(x.to(dev), step)
     assert saved[3] is None                                      # bf16 mode keeps layer inputs only
+    assert torch.equal(eps, eg.eps_only(x.to(dev), step))        # the saving forward runs the chain's own deferred-skip form: same eps, bit for bit
     g = eg.backward(saved, v.to(dev)).cpu()
     eg.fused_bf16 = False
     g_fp32 = eg.backward(saved, v.to(dev)).cpu()                 # same layer inputs, fp32 GEMMs
