@@ -317,6 +317,10 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_bf16_kernel(
   }
 }
 
+#ifdef AP_TOOLS
+__device__ unsigned long long *g_bwdb_stamp = nullptr;           // tools/clock_bwd_bf16.py: [workgroup][2] = (s_memtime, s_memrealtime) ticks around K2's chunk loop
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // K2: one workgroup = one (clip, 64-sample tile); 4 waves x (64 rows x 64 columns), 132 registers: three workgroups per CU.
 // (Measured and not kept, docs/HISTORY.md H: 128-column tiles at two workgroups per CU and 64-column tiles at four per CU -- both 3-7 % slower.)
@@ -380,6 +384,9 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
   issue_y(0);
   store_y(lds);
   __syncthreads();
+#ifdef AP_TOOLS
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
   for (int ch = 0; ch < 12; ch++) {
     const __bf16 *yb = lds + (ch & 1) * YB + j * YSB_ + 8 * hh;
@@ -406,6 +413,12 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
     store_y(lds + ((ch + 1) & 1) * YB);
     __syncthreads();
   }
+#ifdef AP_TOOLS
+  if (g_bwdb_stamp && tid == 0) {                                // the in-kernel clock of the loop: d(s_memtime) / d(s_memrealtime) x 100 MHz
+    g_bwdb_stamp[2 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memtime() - st_t0;
+    g_bwdb_stamp[2 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
   // epilogue: the residual path, fp32 rows out
   const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
   const __amdgpu_buffer_rsrc_t prs = uni_rsrc(dhp + (size_t)b * C * L, clip_bytes);
@@ -465,3 +478,9 @@ extern "C" int ap_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *h_in, c
 }
 
 extern "C" int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L) { return ctx && ap::resblock_bwd_bf16_serves(ctx, B, L) ? 1 : 0; }
+
+#ifdef AP_TOOLS
+extern "C" int ap_debug_bwdb_stamp(void *buf) {                  // buf: device memory, 16 bytes per K2 workgroup (or null: off)
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(ap::g_bwdb_stamp), &buf, sizeof(buf));
+}
+#endif
