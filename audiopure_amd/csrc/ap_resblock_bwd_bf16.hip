@@ -35,6 +35,20 @@ constexpr int DSB_ = 2 * QC_ + 8;         // bf16 per column row of K1's dy tile
 constexpr int YSB_ = 128 + 8;             // bf16 per column row of K2's chunk image (one tap x 128 channels; 272-byte rows)
 constexpr unsigned FRB_ = 64 * 16;        // bytes of one row tile's fragment of a k-step (64 lanes x 8 bf16)
 
+// Workgroup k runs on XCD k mod 8 (round-robin dispatch), and each XCD has its own L2: give every XCD one CONTIGUOUS run of tiles, in
+// dispatch order, so that the tiles holding a tile's +-d taps (up to 32 tiles away) run on the same XCD at about the same time and a
+// row of h / dy is fetched from HBM once, not once per tap.  Bijective for any grid size.
+#ifdef AP_TOOLS
+__device__ int g_bwdb_linear = 0;                                // tools/time_bwd_bf16.py: 1 = tile k on workgroup k (the A/B of this mapping)
+#endif
+__device__ __forceinline__ unsigned xcd_tile(unsigned k, unsigned G) {
+#ifdef AP_TOOLS
+  if (g_bwdb_linear) return k;
+#endif
+  const unsigned x = k & 7u, q = G >> 3, r = G & 7u;
+  return x * q + (x < r ? x : r) + (k >> 3);
+}
+
 __device__ __forceinline__ bf16x8 cvt8(const float (&v)[8]) {
   const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
   return __builtin_convertvector(f, bf16x8);
@@ -120,8 +134,9 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_bf16_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
-  const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ntiles));
-  const int t0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % ntiles) * NT);
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int b = __builtin_amdgcn_readfirstlane((int)(tile / ntiles));
+  const int t0 = __builtin_amdgcn_readfirstlane((int)(tile % ntiles) * NT);
   auto uni_rsrc = [&](const void *base, unsigned bytes) {
     const uint64_t hb = (uint64_t)base;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
@@ -336,8 +351,9 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
-  const int b = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / ntiles));
-  const int t0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % ntiles) * NT);
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int b = __builtin_amdgcn_readfirstlane((int)(tile / ntiles));
+  const int t0 = __builtin_amdgcn_readfirstlane((int)(tile % ntiles) * NT);
   auto uni_rsrc = [&](const void *base, unsigned bytes) {
     const uint64_t hb = (uint64_t)base;
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
@@ -480,6 +496,7 @@ extern "C" int ap_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *h_in, c
 extern "C" int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L) { return ctx && ap::resblock_bwd_bf16_serves(ctx, B, L) ? 1 : 0; }
 
 #ifdef AP_TOOLS
+extern "C" int ap_debug_bwdb_linear(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(ap::g_bwdb_linear), &v, sizeof(v)); }
 extern "C" int ap_debug_bwdb_stamp(void *buf) {                  // buf: device memory, 16 bytes per K2 workgroup (or null: off)
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(ap::g_bwdb_stamp), &buf, sizeof(buf));
 }

@@ -2,6 +2,8 @@
 (under rocprofv3 --kernel-trace --stats for the split between the two kernels)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 3:
+    import _toolslib  # noqa: F401  (the -DAP_TOOLS library)
 from audiopure_amd import synth, _native as N
 from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -27,3 +29,11 @@ def timed(layers=(0, 3, 6, 9, 11), reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (reps * len(layers))
 print(f"B={B} L={L}: {timed()*1e3:.1f} us per layer (both launches)")
+if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaudiopure_hip_tools.so")) and len(sys.argv) > 3:
+    # same-process A/B of the XCD-contiguous tile order (tools build: python tools/time_bwd_bf16.py B L ab, with _toolslib on the path)
+    import ctypes
+    lib.ap_debug_bwdb_linear.argtypes = [ctypes.c_int]
+    for rep in range(3):
+        for name, v in (("tile k on workgroup k", 1), ("one contiguous run of tiles per XCD", 0)):
+            lib.ap_debug_bwdb_linear(v)
+            print(f"  {name}: {timed()*1e3:.1f} us per layer")
