@@ -176,6 +176,9 @@ int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, flo
                              hipStream_t st);                    // returns 1 if the shape is not served (caller: fp32 kernel)
 // `gout` non-null: the deferred-skip form -- the block writes h' and its gate output as a bf16 image [clip][L][256] to gout and
 // leaves `skip` alone; launch_skipgemm_bf16 then adds a group of layers' skip_conv outputs in one GEMM (ap_skipgemm_bf16.hip)
+// ap_resblock_bf16s.hip: the deferred-skip block for launches of at most one 128-sample tile per CU (64-sample tiles, bit-identical results)
+bool resblock_bf16s_serves(const ap_ctx *ctx, int B, int L);
+int launch_resblock_bf16s(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, void *gout, int B, int L, hipStream_t st);
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,

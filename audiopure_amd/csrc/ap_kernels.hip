@@ -502,6 +502,7 @@ __global__ __launch_bounds__(C / 64 * TTK, 2) void resblock_f32_kernel(
 
 AP_TOOLS_VAR g_tile = 64;    // time tile of the residual-block kernel: 64 (4 waves, 2 WG/CU); 128 (8 waves, 1 WG/CU) in tools builds
 AP_TOOLS_VAR g_force_direct = 0;   // tools builds: the direct-form fp32 block even where the minimal-filtering one is built
+AP_TOOLS_VAR g_no_bf16s = 0;  // tools builds: 1 = small bf16 launches stay on the persistent kernel, 2 = every deferred-skip launch on ap_resblock_bf16s.hip (A/B, bit identity)
 AP_TOOLS_VAR g_force_f32 = 0;  // tools builds: run the fp32 kernel even in a bf16 context (A/B timing in one process)
 #ifdef AP_TOOLS
 static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
@@ -534,7 +535,9 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
       AP_HIP(hipEventRecord(e0, st));
     }
     int rc = ctx->cfg.precision == AP_PREC_BF16
-                 ? launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout)
+                 ? (gout && !ub && g_no_bf16s != 1 && (g_no_bf16s == 2 || resblock_bf16s_serves(ctx, B, L))
+                        ? launch_resblock_bf16s(ctx, layer, hin, pt, hout, gout, B, L, st)     // small batches: half-size tiles, bit-identical
+                        : launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout))
                  : launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
     if (e1) AP_HIP(hipEventRecord(e1, st));
     return rc;
@@ -1022,6 +1025,11 @@ extern "C" int ap_debug_tile(int tile) {
 
 extern "C" int ap_debug_force_f32(int on) {
   ap::g_force_f32 = on;
+  return 0;
+}
+
+extern "C" int ap_debug_no_bf16s(int on) {                       // 1: small bf16 launches stay on the persistent kernel
+  ap::g_no_bf16s = on;
   return 0;
 }
 

@@ -922,6 +922,43 @@ def test_bf16_deferred_skip_chain_is_hip_graph_capturable(dh, dev):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("L,Bs,Bl", [(16000, 1, 3), (16000, 2, 5), (4133, 3, 9), (130, 7, 140), (64, 2, 300), (1, 5, 300)])
+def test_bf16_small_batch_block_is_the_persistent_block_bit_for_bit(dev, L, Bs, Bl):
+    """ap_resblock_fwd_gate on a launch of at most one 128-sample tile per CU runs ap_resblock_bf16s.hip (64-sample tiles, one per
+    workgroup); on a larger batch the persistent kernel.  A clip's h' and gate image must not depend on the batch it travels in:
+    the first Bs clips of a Bl-clip launch equal the Bs-clip launch bit for bit, for every dilation, with and without h' (the
+    net's last layer), outputs inside untouched guard bands."""
+    from audiopure_amd import _native as N
+    net, _ = _net(synth.mini_wavenet_config(256, 12, 12), dev, seed=4)
+    net.set_precision("bf16")
+    eng = net.engine()
+    lib = eng.lib
+    tiles = (L + 127) // 128
+    assert Bs * tiles <= 256 < Bl * tiles                        # the two launches are on different kernels
+    h = (torch.rand(Bl, 256, L, device=dev) * 3 - 1.5)
+    pt = torch.rand(256, device=dev) - 0.5
+
+    def run(B, layer, with_h):
+        G = 1024
+        hb = torch.full((B * 256 * L + 2 * G,), 7.25, device=dev)
+        gb = torch.full((B * L * 256 + 2 * G,), 7.25, device=dev, dtype=torch.bfloat16)
+        ho, gi = hb[G:G + B * 256 * L], gb[G:G + B * L * 256]
+        N.check(lib.ap_resblock_fwd_gate(eng.ctx, layer, N.ptr(h[:B].contiguous()), N.ptr(pt), N.ptr(ho) if with_h else None, gi.data_ptr(),
+                                         B, L, N.stream()))
+        for buf, n in ((hb, B * 256 * L), (gb, B * L * 256)):
+            assert bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all()), "write outside the output"
+        if not with_h:
+            assert bool((ho == 7.25).all())                      # h' not wanted: not written
+        return ho.view(B, 256, L), gi.view(B, L, 256)
+
+    for layer in range(12):
+        for with_h in (True, False):
+            hs, gs = run(Bs, layer, with_h)
+            hl, gl = run(Bl, layer, with_h)
+            assert torch.equal(gs.view(torch.int16), gl[:Bs].view(torch.int16)), (layer, with_h)
+            assert torch.equal(hs, hl[:Bs]), (layer, with_h)
+
+
 def test_c_entry_points_match_python_chains(mini, dh, dev):
     """ap_purify_ddpm / ap_purify_sde / ap_one_shot_denoise (coefficients computed inside the library from the installed
     tables) give the same result as the chains the Python classes build with ap_purify_chain."""
