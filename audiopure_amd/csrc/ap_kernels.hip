@@ -140,12 +140,16 @@ int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float swish_acc(float x) { return x / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(512) void embed_mlp_kernel(const float *__restrict__ freq, const float *__restrict__ w1,
+// One workgroup = four rows of fc_t2 (one per wave).  Every workgroup first recomputes all of fc_t1 into LDS -- 65 k multiply-adds
+// read coalesced out of L2, wave-per-row dot products -- so there is no second launch and no grid barrier.  (The one-workgroup form
+// walked each weight row with one thread, 2 KB apart from its neighbour's: 45-60 us of the 1.2 ms a one-clip evaluation takes.)
+__global__ __launch_bounds__(256) void embed_mlp_kernel(const float *__restrict__ freq, const float *__restrict__ w1,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
                                                         const float *__restrict__ b2, float step, int Ein, int Emid,
                                                         int Eout, float *__restrict__ emb_out) {
   extern __shared__ float sm[];
   float *e0 = sm, *e1 = sm + Ein;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int half = Ein / 2;
   for (int i = threadIdx.x; i < half; i += blockDim.x) {
     float a = step * freq[i];
@@ -153,16 +157,19 @@ __global__ __launch_bounds__(512) void embed_mlp_kernel(const float *__restrict_
     e0[half + i] = cosf(a);
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < Emid; o += blockDim.x) {
+  for (int o = wave; o < Emid; o += 4) {
     float s = 0.f;
-    for (int k = 0; k < Ein; k++) s = __builtin_fmaf(w1[(size_t)o * Ein + k], e0[k], s);
-    e1[o] = swish_acc(s + b1[o]);
+    for (int k = lane; k < Ein; k += 64) s = __builtin_fmaf(w1[(size_t)o * Ein + k], e0[k], s);
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) e1[o] = swish_acc(s + b1[o]);
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < Eout; o += blockDim.x) {
+  const int o = blockIdx.x * 4 + wave;
+  if (o < Eout) {
     float s = 0.f;
-    for (int k = 0; k < Emid; k++) s = __builtin_fmaf(w2[(size_t)o * Emid + k], e1[k], s);
-    emb_out[o] = swish_acc(s + b2[o]);
+    for (int k = lane; k < Emid; k += 64) s = __builtin_fmaf(w2[(size_t)o * Emid + k], e1[k], s);
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) emb_out[o] = swish_acc(s + b2[o]);
   }
 }
 
@@ -184,7 +191,7 @@ int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st) {
   // emb vector lives at the tail of part_t's buffer: [NL*C] then [Eout]
   float *emb = part_t + (size_t)ctx->NL * ctx->C;
   size_t sm = (size_t)(c.embed_dim_in + c.embed_dim_mid) * sizeof(float);
-  embed_mlp_kernel<<<1, 512, sm, st>>>(ctx->emb_freq, ctx->fc1_w, ctx->fc1_b, ctx->fc2_w, ctx->fc2_b, step,
+  embed_mlp_kernel<<<(unsigned)((c.embed_dim_out + 3) / 4), 256, sm, st>>>(ctx->emb_freq, ctx->fc1_w, ctx->fc1_b, ctx->fc2_w, ctx->fc2_b, step,
                                        c.embed_dim_in, c.embed_dim_mid, c.embed_dim_out, emb);
   int rows = ctx->NL * ctx->C;
   fct_kernel<<<(rows + 3) / 4, 256, 0, st>>>(ctx->fct_w, ctx->fct_b, emb, part_t, rows, c.embed_dim_out);
