@@ -184,7 +184,9 @@ int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const float *part
  *   ap_ctx_set_skip_group(G): G > 0 makes ap_eps_fwd / ap_purify_* run this form with groups of G layers (the workspace grows
  *                         by G x B x L x C x 2 bytes: ap_workspace_bytes follows); 0 (default) = the fused block per layer.
  * Results: h identical bit for bit; skip differs from the per-layer form by fp32 summation order only (the bf16 products are
- * the same; a group's K = G x 256 is accumulated in the matrix pipe's fp32 accumulators). */
+ * the same; a group's K = G x 256 is accumulated in the matrix pipe's fp32 accumulators).
+ * ap_resblock_fwd_gate launches of at most one 128-sample tile per CU (one or two 1 s clips) run on 64-sample tiles
+ * (ap_resblock_bf16s.hip) with bit-identical results: a clip's h' and g image do not depend on the batch it travels in. */
 int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
                          void *g_image, int B, int L, void *stream);
 int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, float *skip, int accumulate_skip,
