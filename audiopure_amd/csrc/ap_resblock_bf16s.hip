@@ -48,6 +48,8 @@ __device__ __forceinline__ f32x2 gate_pair(f32x2 a, f32x2 b) {
 // 25.2 / 41.7 here; from three clips on the persistent kernel is as fast or faster: 61 against 61 us at B = 3, 70 against 83 at B = 4.)
 // (Also measured and not kept: 64-channel chunks -- four load round trips per tile instead of eight -- at one workgroup per CU: 26.0 against
 // 25.3 us at B = 1.  The tile is bound by the 1.25 MB it moves through its CU's vector-memory path, 0.9 MB of it weight fragments.)
+// (And: two adjacent tiles per 16-wave workgroup, so that the two column halves' waves request the same weight fragments a barrier
+// interval apart and could share them in L1: 43.7 against 42.0 us at B = 2 -- what two tiles on one CU share is its delivery rate.)
 // One workgroup = one (clip, 64-sample tile); 8 waves, wave w = gate channels [32 w, 32 w + 32) in GEMM1 and res rows [32 w, 32 w + 32)
 // in GEMM2.  w1 / w2: this layer's images of ap_resblock_bf16p.hip (pack_w1_bf16_kernel: [wave][chunk 8][k-step 6][row tile 2][lane][8];
 // pack_w2_bf16_kernel: [wave][row tile 2][k-step 16][lane][8], row tile 0 = res rows).
