@@ -140,10 +140,12 @@ int launch_fold_and_pack(ap_ctx *ctx, const float *blob, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float swish_acc(float x) { return x / (1.0f + expf(-x)); }
 
-// One workgroup = four rows of fc_t2 (one per wave).  Every workgroup first recomputes all of fc_t1 into LDS -- 65 k multiply-adds
-// read coalesced out of L2, wave-per-row dot products -- so there is no second launch and no grid barrier.  (The one-workgroup form
-// walked each weight row with one thread, 2 KB apart from its neighbour's: 45-60 us of the 1.2 ms a one-clip evaluation takes.)
-__global__ __launch_bounds__(256) void embed_mlp_kernel(const float *__restrict__ freq, const float *__restrict__ w1,
+// One workgroup of 8 waves = eight rows of fc_t2 (one per wave).  Every workgroup first recomputes all of fc_t1 into LDS -- 65 k
+// multiply-adds, wave-per-row dot products, sixteen rows per pass and wave -- so there is no second launch, no scratch buffer and no grid
+// barrier.  Every load is UNCONDITIONAL (indices clamped, the product masked): a load inside `if (row < Emid)` sits in its own basic
+// block with its own wait, and the sixteen rows of a pass became sixteen round trips (81-115 us; the one-workgroup form that walked each
+// weight row with one thread took 45-60 us per evaluation).
+__global__ __launch_bounds__(512) void embed_mlp_kernel(const float *__restrict__ freq, const float *__restrict__ w1,
                                                         const float *__restrict__ b1, const float *__restrict__ w2,
                                                         const float *__restrict__ b2, float step, int Ein, int Emid,
                                                         int Eout, float *__restrict__ emb_out) {
@@ -157,20 +159,38 @@ __global__ __launch_bounds__(256) void embed_mlp_kernel(const float *__restrict_
     e0[half + i] = cosf(a);
   }
   __syncthreads();
-  for (int o = wave; o < Emid; o += 4) {
-    float s = 0.f;
-    for (int k = lane; k < Ein; k += 64) s = __builtin_fmaf(w1[(size_t)o * Ein + k], e0[k], s);
-    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
-    if (lane == 0) e1[o] = swish_acc(s + b1[o]);
+  for (int o0 = wave; o0 < Emid; o0 += 8 * 16) {
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0.f;
+    for (int kk = 0; kk < Ein; kk += 64) {
+      const int k = min(kk + lane, Ein - 1);
+      const float ev = kk + lane < Ein ? e0[k] : 0.f;             // (a clamped lane contributes 0)
+#pragma unroll
+      for (int i = 0; i < 16; i++) s[i] = __builtin_fmaf(w1[(size_t)min(o0 + 8 * i, Emid - 1) * Ein + k], ev, s[i]);
+    }
+    for (int m = 32; m > 0; m >>= 1) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) s[i] += __shfl_xor(s[i], m);
+    }
+    float mine = 0.f;                                            // lane i takes row i's sum: ONE swish for the sixteen rows
+#pragma unroll
+    for (int i = 0; i < 16; i++) mine = lane == i ? s[i] : mine;
+    const int o = o0 + 8 * lane;
+    if (lane < 16 && o < Emid) e1[o] = swish_acc(mine + b1[o]);
   }
   __syncthreads();
-  const int o = blockIdx.x * 4 + wave;
-  if (o < Eout) {
-    float s = 0.f;
-    for (int k = lane; k < Emid; k += 64) s = __builtin_fmaf(w2[(size_t)o * Emid + k], e1[k], s);
-    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
-    if (lane == 0) emb_out[o] = swish_acc(s + b2[o]);
+  const int o2 = min((int)blockIdx.x * 8 + wave, Eout - 1);      // (a wave past the last row recomputes it and does not store)
+  float s = 0.f;
+  for (int kk = 0; kk < Emid; kk += 512) {
+    float wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) wv[i] = w2[(size_t)o2 * Emid + min(kk + 64 * i + lane, Emid - 1)];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s = kk + 64 * i + lane < Emid ? __builtin_fmaf(wv[i], e1[kk + 64 * i + lane], s) : s;
   }
+  for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0 && (int)blockIdx.x * 8 + wave < Eout) emb_out[o2] = swish_acc(s + b2[o2]);
 }
 
 // part_t[row] = fct_w[row] . emb + fct_b[row]; one wave per row, rows = NL*C
@@ -191,7 +211,7 @@ int launch_embed(ap_ctx *ctx, float step, float *part_t, hipStream_t st) {
   // emb vector lives at the tail of part_t's buffer: [NL*C] then [Eout]
   float *emb = part_t + (size_t)ctx->NL * ctx->C;
   size_t sm = (size_t)(c.embed_dim_in + c.embed_dim_mid) * sizeof(float);
-  embed_mlp_kernel<<<(unsigned)((c.embed_dim_out + 3) / 4), 256, sm, st>>>(ctx->emb_freq, ctx->fc1_w, ctx->fc1_b, ctx->fc2_w, ctx->fc2_b, step,
+  embed_mlp_kernel<<<(unsigned)((c.embed_dim_out + 7) / 8), 512, sm, st>>>(ctx->emb_freq, ctx->fc1_w, ctx->fc1_b, ctx->fc2_w, ctx->fc2_b, step,
                                        c.embed_dim_in, c.embed_dim_mid, c.embed_dim_out, emb);
   int rows = ctx->NL * ctx->C;
   fct_kernel<<<(rows + 3) / 4, 256, 0, st>>>(ctx->fct_w, ctx->fct_b, emb, part_t, rows, c.embed_dim_out);
