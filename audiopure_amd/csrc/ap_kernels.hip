@@ -201,7 +201,17 @@ __global__ void fct_kernel(const float *__restrict__ w, const float *__restrict_
   if (row >= rows) return;
   const float *p = w + (size_t)row * E;
   float s = 0.f;
-  for (int i = lane; i < E; i += 64) s = __builtin_fmaf(p[i], emb[i], s);
+  for (int i0 = 0; i0 < E; i0 += 512) {                          // eight loads per operand out together (clamped; a lane past E adds 0), then the sum in order
+    float wv[8], ev[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = min(i0 + 64 * u + lane, E - 1);
+      wv[u] = p[i];
+      ev[u] = emb[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) s = i0 + 64 * u + lane < E ? __builtin_fmaf(wv[u], ev[u], s) : s;
+  }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) out[row] = s + b[row];
 }
