@@ -57,21 +57,9 @@ __device__ __forceinline__ bf16x8 cvt8(const float (&v)[8]) {
 }  // namespace
 
 // ---- weight images (bf16, RNE) -----------------------------------------------------------------------------------------------
-// K1, y:  [wave 8][chunk 8][k-step 6][row tile 2][lane 64][8]; k-step ks of chunk ch: tap ks / 2, channel 32 ch + 16 (ks & 1) + 8 hh + jj;
-//         row tile rt: rt C + 32 wave + i  (0 = tanh rows, 1 = sigmoid rows of the wave's 32 gate channels)
-__global__ void pack_bw_w1y_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out) {
-  constexpr int C = QC_;
-  const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 8u * 8 * 6 * 2 * 64 * 8) return;
-  const int jj = idx & 7, lane = (idx >> 3) & 63, rt = (idx >> 9) & 1;
-  unsigned rest = idx >> 10;
-  const int ks = rest % 6; rest /= 6;
-  const int ch = rest & 7, w = rest >> 3;
-  const int i = lane & 31, hh = lane >> 5;
-  const int tap = ks >> 1, c = 32 * ch + 16 * (ks & 1) + 8 * hh + jj;
-  const int o = rt * C + 32 * w + i;
-  out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + tap];
-}
+// K1, y:  the forward's GEMM1 image itself (ap_resblock_bf16p.hip, pack_w1_bf16_kernel: [wave 8][chunk 8][k-step 6][row tile 2][lane 64][8];
+//         k-step ks of chunk ch: tap ks / 2, channel 32 ch + 16 (ks & 1) + 8 hh + jj; row tile rt: rt C + 32 wave + i) -- the recomputation
+//         reads the very fragments the forward multiplied with.
 // K1, dg: [wave 8][k-step 32][lane 64][8]; k = 16 ks + 8 hh + jj over [res output (256); skip output (256)];
 //         row c = 32 wave + i; value W2[k][c], the res half times sqrt(1/2)
 __global__ void pack_bw_w2t_kernel(const float *__restrict__ w2f, __bf16 *__restrict__ out) {
@@ -100,16 +88,15 @@ __global__ void pack_bw_w1b_kernel(const float *__restrict__ w1f, __bf16 *__rest
   out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + (2 - tp)];
 }
 
-constexpr size_t BW_W1Y_ = (size_t)8 * 8 * 6 * 2 * 64 * 8, BW_W2T_ = (size_t)8 * 32 * 64 * 8, BW_W1B_ = (size_t)4 * 12 * 8 * 2 * 64 * 8;
+constexpr size_t BW_W2T_ = (size_t)8 * 32 * 64 * 8, BW_W1B_ = (size_t)4 * 12 * 8 * 2 * 64 * 8;
 
 static int launch_pack_bwd_bf16(ap_ctx *ctx, hipStream_t st) {
   const size_t n1f = (size_t)2 * QC_ * QC_ * 3, n2 = (size_t)2 * QC_ * QC_;
   __bf16 *base = (__bf16 *)ctx->slab_bb;
   for (int n = 0; n < ctx->NL; n++) {
-    __bf16 *p = base + (size_t)n * (BW_W1Y_ + BW_W2T_ + BW_W1B_);
-    pack_bw_w1y_kernel<<<(unsigned)((BW_W1Y_ + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1f, p);
-    pack_bw_w2t_kernel<<<(unsigned)((BW_W2T_ + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, p + BW_W1Y_);
-    pack_bw_w1b_kernel<<<(unsigned)((BW_W1B_ + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1f, p + BW_W1Y_ + BW_W2T_);
+    __bf16 *p = base + (size_t)n * (BW_W2T_ + BW_W1B_);
+    pack_bw_w2t_kernel<<<(unsigned)((BW_W2T_ + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, p);
+    pack_bw_w1b_kernel<<<(unsigned)((BW_W1B_ + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1f, p + BW_W2T_);
   }
   AP_HIP(hipGetLastError());
   return 0;
@@ -468,17 +455,18 @@ int launch_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *hin, const flo
     set_error("ap_resblock_bwd_bf16: built for AP_PREC_BF16 with res = skip = 256 channels and clips below 2^20 samples");
     return -22;
   }
-  if (!ctx->slab_bb) {                                           // first bf16 backward call of this context: the three weight images
-    AP_HIP(hipMalloc(&ctx->slab_bb, (size_t)ctx->NL * (BW_W1Y_ + BW_W2T_ + BW_W1B_) * 2));
+  if (!ctx->slab_bb) {                                           // first bf16 backward call of this context: its two own weight images
+    AP_HIP(hipMalloc(&ctx->slab_bb, (size_t)ctx->NL * (BW_W2T_ + BW_W1B_) * 2));
     int rc = launch_pack_bwd_bf16(ctx, st);
     if (rc) return rc;
   }
-  const __bf16 *p = (const __bf16 *)ctx->slab_bb + (size_t)layer * (BW_W1Y_ + BW_W2T_ + BW_W1B_);
+  const __bf16 *p = (const __bf16 *)ctx->slab_bb + (size_t)layer * (BW_W2T_ + BW_W1B_);
+  const __bf16 *w1y = (const __bf16 *)ctx->w1p_bf + (size_t)layer * ((size_t)2 * QC_ * QC_ * 3);   // the forward's GEMM1 image
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const int nt = (L + 63) / 64, nt4 = (L + 127) / 128;
-  resblock_bwd_gate_bf16_kernel<<<(unsigned)(B * nt4), 512, 0, st>>>(hin, pt, dhp, dskip, (__bf16 *)dy, p, ctx->b1 + (size_t)layer * 2 * QC_,
-                                                                     p + BW_W1Y_, L, d, nt4);
-  resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W1Y_ + BW_W2T_, L, d, nt);
+  resblock_bwd_gate_bf16_kernel<<<(unsigned)(B * nt4), 512, 0, st>>>(hin, pt, dhp, dskip, (__bf16 *)dy, w1y, ctx->b1 + (size_t)layer * 2 * QC_,
+                                                                     p, L, d, nt4);
+  resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W2T_, L, d, nt);
   AP_HIP(hipGetLastError());
   return 0;
 }
