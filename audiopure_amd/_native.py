@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("AUDIOPURE_HIP_LIB") or os.path.join(_HERE, "lib", "li
 AP_PREC_F32 = 0
 AP_PREC_BF16 = 1
 AP_PREC_F32_SPLIT = 2
+AP_PREC_BF16_STORE = 4
 
 
 class NativeError(RuntimeError):
@@ -60,6 +61,9 @@ SIGNATURES = {
     "ap_resblock_fwd_save": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     "ap_resblock_bwd": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
     "ap_resblock_bwd_available": (_i, [_vp, _i, _i]),
+    "ap_ctx_prepare_backward": (_i, [_vp, _vp]),
+    "ap_init_conv_u": (_i, [_vp, _fp, _fp, _vp, _i, _i, _vp]),
+    "ap_resblock_fwd_u": (_i, [_vp, _i, _vp, _fp, _vp, _vp, _i, _i, _vp]),
     "ap_resblock_bwd_bf16": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _vp, _fp, _i, _i, _vp]),
     "ap_resblock_bwd_bf16_available": (_i, [_vp, _i, _i]),
     "ap_resblock_fwd_gate": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _i, _i, _vp]),

@@ -64,12 +64,12 @@ static int check_cfg(const ap_config &c) {
     set_error("config: invalid layer/embedding/schedule sizes");
     return -22;
   }
-  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16 && c.precision != AP_PREC_F32_SPLIT) {
-    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16, AP_PREC_F32_SPLIT)", c.precision);
+  if (c.precision != AP_PREC_F32 && c.precision != AP_PREC_BF16 && c.precision != AP_PREC_F32_SPLIT && c.precision != AP_PREC_BF16_STORE) {
+    set_error("config: precision %d not built (AP_PREC_F32, AP_PREC_BF16, AP_PREC_F32_SPLIT, AP_PREC_BF16_STORE)", c.precision);
     return -22;
   }
   if (c.precision != AP_PREC_F32 && c.res_channels != 256) {
-    set_error("config: AP_PREC_BF16 / AP_PREC_F32_SPLIT are built for res_channels = 256 only (got %d)",
+    set_error("config: AP_PREC_BF16 / AP_PREC_BF16_STORE / AP_PREC_F32_SPLIT are built for res_channels = 256 only (got %d)",
               c.res_channels);
     return -22;
   }
@@ -106,6 +106,7 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->slab_b = nullptr;
   c->slab_bb = nullptr;
   c->w2t = c->w1b = nullptr;
+  c->bwd_ready = false;
   c->f32_form = 1;
   c->w1p_s = c->w2p_s = nullptr;
   c->profile = false;
@@ -192,8 +193,8 @@ extern "C" int ap_profile_read_split(ap_ctx *ctx, double *ms_by_kind, int64_t *l
 extern "C" int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group) {
   if (!ctx) { set_error("ap_ctx_set_skip_group: null ctx"); return -22; }
   if (layers_per_group < 0 || layers_per_group > ctx->NL) { set_error("ap_ctx_set_skip_group: %d outside [0, %d]", layers_per_group, ctx->NL); return -22; }
-  if (layers_per_group > 0 && (ctx->cfg.precision != AP_PREC_BF16 || ctx->C != 256 || ctx->S != 256)) {
-    set_error("ap_ctx_set_skip_group: the deferred-skip form is built for AP_PREC_BF16 with res = skip = 256 channels");
+  if (layers_per_group > 0 && ((ctx->cfg.precision != AP_PREC_BF16 && ctx->cfg.precision != AP_PREC_BF16_STORE) || ctx->C != 256 || ctx->S != 256)) {
+    set_error("ap_ctx_set_skip_group: the deferred-skip form is built for AP_PREC_BF16 / AP_PREC_BF16_STORE with res = skip = 256 channels");
     return -22;
   }
   ctx->skip_group = layers_per_group;
@@ -281,18 +282,8 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
   AP_HIP(hipMemcpyAsync(ctx->emb_freq, embed_freq_dev, sizeof(float) * (Ein / 2), hipMemcpyDeviceToDevice, st));
   int rc = launch_fold_and_pack(ctx, blob_dev, st);
   if (rc) return rc;
-  if (ctx->slab_b) {                                            // (re-loaded weights: the backward images are rebuilt at the next backward call)
-    AP_HIP(hipStreamSynchronize(st));
-    (void)hipFree(ctx->slab_b);
-    ctx->slab_b = nullptr;
-    ctx->w2t = ctx->w1b = nullptr;
-  }
-  if (ctx->slab_bb) {
-    AP_HIP(hipStreamSynchronize(st));
-    (void)hipFree(ctx->slab_bb);
-    ctx->slab_bb = nullptr;
-  }
-  if (c.precision == AP_PREC_BF16) {
+  ctx->bwd_ready = false;                                       // (re-loaded weights: the backward images are rebuilt by the next ap_ctx_prepare_backward)
+  if (c.precision == AP_PREC_BF16 || c.precision == AP_PREC_BF16_STORE) {
     const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
     if (!ctx->slab_bf) {
 #ifdef AP_TOOLS                                                   // + the 16x16x32 GEMM1 image of the tools library's M16 instantiation
@@ -335,6 +326,16 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
   return 0;
 }
 
+extern "C" int ap_ctx_prepare_backward(ap_ctx *ctx, void *stream) {
+  if (!ctx || !ctx->loaded) { set_error("ap_ctx_prepare_backward: weights not loaded (ap_ctx_load_wavenet)"); return -22; }
+  if (ctx->bwd_ready) return 0;
+  if (ctx->C != 256 || ctx->S != 256) { set_error("ap_ctx_prepare_backward: the fused backward kernels are built for res = skip = 256 channels"); return -22; }
+  if (ctx->cfg.precision == AP_PREC_F32) return prepare_bwd_f32(ctx, (hipStream_t)stream);
+  if (ctx->cfg.precision == AP_PREC_BF16) return prepare_bwd_bf16(ctx, (hipStream_t)stream);
+  set_error("ap_ctx_prepare_backward: no fused backward in precision %d (AP_PREC_F32, AP_PREC_BF16)", ctx->cfg.precision);
+  return -22;
+}
+
 extern "C" int ap_ctx_get_folded(ap_ctx *ctx, int which, int layer, float *out_dev, size_t n_elems, void *stream) {
   if (!ctx || !ctx->loaded || !out_dev) { set_error("get_folded: context not loaded / null"); return -22; }
   const size_t C = ctx->C, S = ctx->S;
@@ -356,6 +357,8 @@ extern "C" int ap_ctx_get_folded(ap_ctx *ctx, int which, int layer, float *out_d
 
 // workspace: h_a [B C L] | h_b [B C L] | skip [B S L] | x_a [B L] | x_b [B L] | part_t [NL C + Eout]
 //            | AP_PREC_BF16 with a skip group G > 0: g images [G][B][L][C] bf16 (the deferred-skip form: ap_skipgemm_bf16.hip)
+// AP_PREC_BF16_STORE: h_a, h_b are the bf16 u images [B][C/32][L][32] (half the bytes); always the deferred-skip form (G = 0 means
+//            one group of all layers)
 //            | tools builds, AP_PREC_BF16: ub_a, ub_b [B][C/32][L][32] bf16 (the operand-image experiment: ap_resblock_bf16p.hip, UB)
 #ifdef AP_TOOLS
 namespace ap { extern int g_dbg_bf16; }
@@ -369,9 +372,14 @@ struct Ws {
   size_t bytes;
 };
 inline size_t al(size_t n) { return (n + 63) & ~(size_t)63; }
+inline int skip_group_of(const ap_ctx *ctx) {                    // layers per skip GEMM; 0: the fused block (skip per layer)
+  if (ctx->cfg.precision == AP_PREC_BF16_STORE) return ctx->skip_group > 0 ? ctx->skip_group : ctx->NL;
+  return ctx->cfg.precision == AP_PREC_BF16 ? ctx->skip_group : 0;
+}
 Ws carve(const ap_ctx *ctx, void *base, int B, int L) {
   Ws w;
-  size_t act = al((size_t)B * ctx->C * L), sk = al((size_t)B * ctx->S * L), xl = al((size_t)B * L),
+  const bool bstore = ctx->cfg.precision == AP_PREC_BF16_STORE;
+  size_t act = al(bstore ? ((size_t)B * ctx->C * L + 1) / 2 : (size_t)B * ctx->C * L), sk = al((size_t)B * ctx->S * L), xl = al((size_t)B * L),
          pt = al((size_t)ctx->NL * ctx->C + ctx->cfg.embed_dim_out);
   float *p = (float *)base;
   w.ha = p; p += act;
@@ -383,10 +391,10 @@ Ws carve(const ap_ctx *ctx, void *base, int B, int L) {
   w.uba = w.ubb = nullptr;
   w.gimg = nullptr;
   w.gslot = 0;
-  if (ctx->cfg.precision == AP_PREC_BF16 && ctx->skip_group > 0) {
+  if (skip_group_of(ctx) > 0) {
     w.gslot = (size_t)B * L * ctx->C * 2;                       // (a multiple of 512 bytes)
     w.gimg = (char *)p;
-    p += al(((size_t)ctx->skip_group * w.gslot + 3) / 4);
+    p += al(((size_t)skip_group_of(ctx) * w.gslot + 3) / 4);
   }
 #ifdef AP_TOOLS
   if (ctx->cfg.precision == AP_PREC_BF16) {
@@ -409,9 +417,75 @@ int check_run(ap_ctx *ctx, int B, int L, void *ws, size_t ws_bytes, const char *
 }
 
 // the 36-layer sweep: h ping-pongs between ha/hb, skip accumulates (WaveNet.py:120-135,164-170)
+// one AP_PREC_BF16_STORE block launch (its own pair of profile events: kind 0)
+int launch_resblock_u_timed(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profile) {
+    if (ctx->ev_used + 2 > ctx->ev.size())
+      for (int i = 0; i < 2; i++) {
+        hipEvent_t e;
+        AP_HIP(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+      }
+    e0 = ctx->ev[ctx->ev_used];
+    e1 = ctx->ev[ctx->ev_used + 1];
+    if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
+    ctx->ev_kind[ctx->ev_used / 2] = 0;
+    ctx->ev_used += 2;
+    AP_HIP(hipEventRecord(e0, st));
+  }
+  const int rc = launch_resblock_bf16u(ctx, layer, uin, pt_next, uout, gout, B, L, st);
+  if (e1) AP_HIP(hipEventRecord(e1, st));
+  return rc;
+}
+
+// one skip GEMM (its own pair of profile events: kind 1)
+int skip_gemm_timed(ap_ctx *ctx, int n0, int nl, const Ws &w, int B, int L, hipStream_t st) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ctx->profile) {
+    if (ctx->ev_used + 2 > ctx->ev.size())
+      for (int i = 0; i < 2; i++) {
+        hipEvent_t e;
+        AP_HIP(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+      }
+    e0 = ctx->ev[ctx->ev_used];
+    e1 = ctx->ev[ctx->ev_used + 1];
+    if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
+    ctx->ev_kind[ctx->ev_used / 2] = 1;
+    ctx->ev_used += 2;
+    AP_HIP(hipEventRecord(e0, st));
+  }
+  const int rc = launch_skipgemm_bf16(ctx, n0, nl, w.gimg, w.skip, n0 > 0, B, L, st);
+  if (e1) AP_HIP(hipEventRecord(e1, st));
+  return rc;
+}
+
+// AP_PREC_BF16_STORE: the sweep over bf16 u images (ap_resblock_bf16u.hip), skip through the deferred-skip GEMM
+int run_net_bstore(ap_ctx *ctx, const float *x, const Ws &w, int B, int L, hipStream_t st) {
+  int rc = launch_init_conv_u(ctx, x, w.pt, w.ha, B, L, st);
+  if (rc) return rc;
+  void *uin = w.ha, *uout = w.hb;
+  const int G = skip_group_of(ctx);
+  for (int n0 = 0; n0 < ctx->NL; n0 += G) {
+    const int nl = ctx->NL - n0 < G ? ctx->NL - n0 : G;
+    for (int n = n0; n < n0 + nl; n++) {
+      const bool last = n + 1 == ctx->NL;
+      rc = launch_resblock_u_timed(ctx, n, uin, last ? nullptr : w.pt + (size_t)(n + 1) * ctx->C, last ? nullptr : uout,
+                                   w.gimg + (size_t)(n - n0) * w.gslot, B, L, st);
+      if (rc) return rc;
+      void *t = uin; uin = uout; uout = t;
+    }
+    rc = skip_gemm_timed(ctx, n0, nl, w, B, L, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int run_net(ap_ctx *ctx, const float *x, float step, const Ws &w, int B, int L, hipStream_t st) {
   int rc = launch_embed(ctx, step, w.pt, st);
   if (rc) return rc;
+  if (ctx->cfg.precision == AP_PREC_BF16_STORE) return run_net_bstore(ctx, x, w, B, L, st);
   rc = launch_init_conv(ctx, x, w.ha, B, L, st);
   if (rc) return rc;
   float *hin = w.ha, *hout = w.hb;
@@ -446,23 +520,7 @@ int run_net(ap_ctx *ctx, const float *x, float step, const Ws &w, int B, int L, 
         if (rc) return rc;
         float *t = hin; hin = hout; hout = t;
       }
-      hipEvent_t e0 = nullptr, e1 = nullptr;
-      if (ctx->profile) {
-        if (ctx->ev_used + 2 > ctx->ev.size())
-          for (int i = 0; i < 2; i++) {
-            hipEvent_t e;
-            AP_HIP(hipEventCreate(&e));
-            ctx->ev.push_back(e);
-          }
-        e0 = ctx->ev[ctx->ev_used];
-        e1 = ctx->ev[ctx->ev_used + 1];
-        if (ctx->ev_kind.size() < ctx->ev.size() / 2) ctx->ev_kind.resize(ctx->ev.size() / 2, 0);
-        ctx->ev_kind[ctx->ev_used / 2] = 1;
-        ctx->ev_used += 2;
-        AP_HIP(hipEventRecord(e0, st));
-      }
-      rc = launch_skipgemm_bf16(ctx, n0, nl, w.gimg, w.skip, n0 > 0, B, L, st);
-      if (e1) AP_HIP(hipEventRecord(e1, st));
+      rc = skip_gemm_timed(ctx, n0, nl, w, B, L, st);
       if (rc) return rc;
     }
     return 0;
@@ -494,6 +552,21 @@ extern "C" int ap_init_conv(ap_ctx *ctx, const float *x, float *h, int B, int L,
   return launch_init_conv(ctx, x, h, B, L, (hipStream_t)stream);
 }
 
+extern "C" int ap_init_conv_u(ap_ctx *ctx, const float *x, const float *part_t_layer0, void *u_out, int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !x || !part_t_layer0 || !u_out || B < 1 || L < 1) { set_error("ap_init_conv_u: bad argument"); return -22; }
+  if (!resblock_bf16u_serves(ctx, L)) { set_error("ap_init_conv_u: AP_PREC_BF16_STORE contexts with res = skip = 256 channels only"); return -22; }
+  return launch_init_conv_u(ctx, x, part_t_layer0, u_out, B, L, (hipStream_t)stream);
+}
+
+extern "C" int ap_resblock_fwd_u(ap_ctx *ctx, int layer, const void *u_in, const float *part_t_next, void *u_out, void *g_image, int B, int L,
+                                 void *stream) {
+  if (!ctx || !ctx->loaded || !u_in || !g_image) { set_error("ap_resblock_fwd_u: not loaded / null"); return -22; }
+  if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd_u: layer=%d B=%d L=%d", layer, B, L); return -22; }
+  if (u_out && !part_t_next) { set_error("ap_resblock_fwd_u: u_out needs the next layer's part_t"); return -22; }
+  if (u_in == u_out) { set_error("ap_resblock_fwd_u: u_out must not alias u_in"); return -22; }
+  return launch_resblock_u_timed(ctx, layer, u_in, part_t_next, u_out, g_image, B, L, (hipStream_t)stream);
+}
+
 extern "C" int ap_resblock_fwd(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
                                float *skip, int accumulate_skip, int B, int L, void *stream) {
   if (!ctx || !ctx->loaded || !h_in || !part_t_layer || !h_out || !skip) { set_error("ap_resblock_fwd: not loaded / null"); return -22; }
@@ -514,7 +587,7 @@ extern "C" int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, c
 extern "C" int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, float *skip, int accumulate_skip,
                             int B, int L, void *stream) {
   if (!ctx || !ctx->loaded || !g_images || !skip) { set_error("ap_skip_gemm: not loaded / null"); return -22; }
-  if (ctx->cfg.precision != AP_PREC_BF16) { set_error("ap_skip_gemm: AP_PREC_BF16 only"); return -22; }
+  if (ctx->cfg.precision != AP_PREC_BF16 && ctx->cfg.precision != AP_PREC_BF16_STORE) { set_error("ap_skip_gemm: AP_PREC_BF16 / AP_PREC_BF16_STORE only"); return -22; }
   return launch_skipgemm_bf16(ctx, layer0, n_layers, g_images, skip, accumulate_skip, B, L, (hipStream_t)stream);
 }
 

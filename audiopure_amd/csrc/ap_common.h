@@ -22,6 +22,21 @@ int hip_fail(hipError_t e, const char *what);
     if (_e != hipSuccess) return ap::hip_fail(_e, #x); \
   } while (0)
 
+// CU count of the calling thread's current HIP device (the persistent kernels launch one workgroup per CU).  One table entry per
+// device: a process may drive several devices, and their CU counts / partition modes may differ.  A racing first call writes the
+// same value twice.
+inline int device_cu_count() {
+  static int n_cu_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (n_cu_of[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    n_cu_of[dev] = n;
+  }
+  return n_cu_of[dev];
+}
+
 // Timing-only hooks (ablation masks, phase stamps, dispatch overrides: tools/*.py) exist only in a -DAP_TOOLS build
 // (`python __graft_entry__.py --tools` -> tools/lib/libaudiopure_hip_tools.so).  The shipped library has no `ablate` kernel
 // argument, no ap_debug_* symbol and no stamped instantiation.
@@ -83,9 +98,10 @@ struct ap_ctx {
   void *slab_s;
   float *w1w, *w2w;         // AP_PREC_F32, C = S = 256: F(2,3)-transformed GEMM1 image and GEMM2 image of ap_resblock_f32w.hip, own allocation
   void *slab_w;
-  float *w2t, *w1b;         // backward images of ap_resblock_bwd.hip (allocated at the first backward call), own allocation
+  float *w2t, *w1b;         // backward images of ap_resblock_bwd.hip (ap_ctx_prepare_backward), own allocation
   void *slab_b;
-  void *slab_bb;            // bf16 backward images of ap_resblock_bwd_bf16.hip (allocated at the first bf16 backward call)
+  void *slab_bb;            // bf16 backward images of ap_resblock_bwd_bf16.hip (ap_ctx_prepare_backward)
+  bool bwd_ready;           // the backward images of this context's precision are built from the weights now loaded
   int f32_form;             // AP_PREC_F32: 1 = minimal-filtering (Winograd) block where built (default), 0 = direct-form block
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
@@ -183,6 +199,10 @@ int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *
                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);   // persistent form; returns 1 if the shape is not served
+// AP_PREC_BF16_STORE (ap_resblock_bf16u.hip): the residual stream as bf16 images of u = h + part_t, [clip][C / 32][L][32]
+bool resblock_bf16u_serves(const ap_ctx *ctx, int L);
+int launch_init_conv_u(ap_ctx *ctx, const float *x, const float *pt0, void *u, int B, int L, hipStream_t st);
+int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st);   // uout null: the net's last layer
 int launch_skipgemm_bf16(ap_ctx *ctx, int layer0, int nl, const void *gimg, float *skip, int accumulate, int B, int L, hipStream_t st);
 int launch_resblock_bf16w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);   // one wave per SIMD; returns 1 if the shape is not served
@@ -193,6 +213,8 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
 int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);
+int prepare_bwd_f32(ap_ctx *ctx, hipStream_t st);                // ap_ctx_prepare_backward, per precision (allocate + pack + synchronise)
+int prepare_bwd_bf16(ap_ctx *ctx, hipStream_t st);
 int launch_m5(ap_m5 *m, const float *x, float *logprobs, int B, int L, hipStream_t st);
 int launch_m5_bwd(ap_m5 *m, const float *x, const float *dlogp, float *dx, int B, int L, hipStream_t st);
 int launch_m5_fold(ap_m5 *m, const float *blob, float bn_eps, hipStream_t st);

@@ -551,6 +551,10 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
     set_error("ap_resblock_fwd_save: fp32 arithmetic only (the other modes recompute the pre-gate activations)");
     return -22;
   }
+  if (ctx->cfg.precision == AP_PREC_BF16_STORE) {
+    set_error("AP_PREC_BF16_STORE: the residual stream is a bf16 image in this mode (ap_init_conv_u / ap_resblock_fwd_u), not an fp32 tensor");
+    return -22;
+  }
   if (gout && (ctx->cfg.precision != AP_PREC_BF16 || g_force_f32)) {
     set_error("deferred-skip form: AP_PREC_BF16 only");
     return -22;
@@ -974,7 +978,7 @@ int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, flo
 int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st) {
-  if (ctx->cfg.precision == AP_PREC_BF16) {                     // bf16 mode: the 1x1 convs of final_conv on the bf16 pipe as well
+  if (ctx->cfg.precision == AP_PREC_BF16 || ctx->cfg.precision == AP_PREC_BF16_STORE) {   // bf16 modes: the 1x1 convs of final_conv on the bf16 pipe as well
     const int rc = launch_final_affine_bf16(ctx, skip, x, eps_out, out, ca, cb, cs, z, seed, draw, utt_offset, B, L, st);
     if (rc != 1) return rc;
   }

@@ -73,7 +73,9 @@ using I3 = std::integral_constant<int, 3>;
 // ---- weight images -------------------------------------------------------------------------------------------
 // GEMM1: [wave C/32][chunk C/32][kstep 6][rowtile 2][lane 64][8]; wave w owns gate channels [32w, 32w+32):
 // row tile 0 = tanh rows, 1 = sigmoid rows; k-step ks of a chunk = tap ks/2, channels ch*32 + (ks&1)*16 + 8h + jj.
-__global__ void pack_w1_bf16_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out, int C) {
+// perm (AP_PREC_BF16_STORE): the K order inside a chunk follows the channel order of the u image's rows -- position p holds the
+// chunk's channel (p with bits 2 and 3 swapped), the order of a 32 x 32 accumulator tile's registers (ap_resblock_bf16u.hip).
+__global__ void pack_w1_bf16_kernel(const float *__restrict__ w1f, __bf16 *__restrict__ out, int C, int perm) {
   const int NW = C / 32, NCH = C / KC_;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)NW * NCH * 6 * 2 * 64 * 8;
@@ -87,7 +89,9 @@ __global__ void pack_w1_bf16_kernel(const float *__restrict__ w1f, __bf16 *__res
   int w = rest / NCH;
   int i = lane & 31, hh = lane >> 5;
   int tap = ks >> 1;
-  int c = ch * KC_ + (ks & 1) * 16 + 8 * hh + jj;
+  int pos = (ks & 1) * 16 + 8 * hh + jj;
+  if (perm) pos = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+  int c = ch * KC_ + pos;
   int o = rt * C + 32 * w + i;
   out[idx] = (__bf16)w1f[((size_t)o * C + c) * 3 + tap];
 }
@@ -150,7 +154,8 @@ int launch_pack_bf16(ap_ctx *ctx, hipStream_t st) {
   const int C = ctx->C, S = ctx->S, NL = ctx->NL;
   for (int n = 0; n < NL; n++) {
     size_t n1 = (size_t)2 * C * C * 3, n2 = (size_t)(C + S) * C;
-    pack_w1_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1p_bf + n * n1, C);
+    pack_w1_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1p_bf + n * n1, C,
+                                                                             ctx->cfg.precision == AP_PREC_BF16_STORE ? 1 : 0);
     pack_w2_bf16_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, st>>>(ctx->w2f + n * n2, (__bf16 *)ctx->w2p_bf + n * n2, C);
     if (ctx->w1q_bf && C == 256)
       pack_w1q_bf16_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, st>>>(ctx->w1f + n * n1, (__bf16 *)ctx->w1q_bf + n * n1, C);
@@ -1165,15 +1170,7 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
   // staging form: one window for the three taps where they overlap (d <= 32), else three tap loads
   const int ws = d == 1 ? 1 : d == 2 ? 2 : (d <= 32 && d % 4 == 0) ? 0 : d < 4 ? -2 : -1;
   if (ws == -2) return 1;                                        // (d = 3: no such dilation in a power-of-two cycle)
-  static int n_cu_of[64] = {0};                                  // CU count per HIP device (the grid is one workgroup per CU)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (n_cu_of[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-    n_cu_of[dev] = n;
-  }
-  const int n_cu = n_cu_of[dev];
+  const int n_cu = device_cu_count();                            // (the grid is one workgroup per CU)
   const int ntiles = (L + PT_ - 1) / PT_;
   const int nblk = B * ntiles;
   int grid = nblk < n_cu ? nblk : n_cu;

@@ -377,8 +377,6 @@ __global__ __launch_bounds__(256, 1) void resblock_bwd_conv_kernel(const float *
   }
 }
 
-static int g_ncu_b = 0;
-
 bool resblock_bwd_serves(const ap_ctx *ctx, int B, int L) {
   if (ctx->cfg.precision != AP_PREC_F32 || ctx->C != BC_ || ctx->S != BC_ || !ctx->loaded) return false;
   if ((size_t)2 * BC_ * (size_t)L * 4 >= ((size_t)1 << 31)) return false;
@@ -392,20 +390,11 @@ int launch_resblock_bwd(ap_ctx *ctx, int layer, const float *dhp, const float *d
     set_error("ap_resblock_bwd: built for AP_PREC_F32 with res = skip = 256 channels and clips below 2^20 samples");
     return -22;
   }
-  if (!ctx->w2t) {                                               // first backward call of this context: the two weight images
-    const size_t n1b = (size_t)ctx->NL * 4 * 2 * BC_ * BC_, n2 = (size_t)ctx->NL * 2 * BC_ * BC_;
-    AP_HIP(hipMalloc(&ctx->slab_b, (n1b + n2) * sizeof(float)));
-    ctx->w1b = (float *)ctx->slab_b;
-    ctx->w2t = ctx->w1b + n1b;
-    int rc = launch_pack_bwd(ctx, st);
-    if (rc) return rc;
+  if (!ctx->bwd_ready) {                                         // (launch functions allocate nothing: include/audiopure.h)
+    set_error("ap_resblock_bwd: the backward weight images are not built (ap_ctx_prepare_backward after every ap_ctx_load_wavenet)");
+    return -22;
   }
-  if (g_ncu_b == 0) {
-    int dev = 0, n = 0;
-    AP_HIP(hipGetDevice(&dev));
-    AP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    g_ncu_b = n > 0 ? n : 256;
-  }
+  const int g_ncu_b = device_cu_count();
   const int C = BC_;
   const int nt1 = (L + 63) / 64;
   resblock_bwd_gate_kernel<<<(unsigned)(B * nt1), 256, 0, st>>>(dhp, dskip, pre, dy, ctx->w2t + (size_t)layer * 2 * C * C, L, nt1);
@@ -417,6 +406,29 @@ int launch_resblock_bwd(ap_ctx *ctx, int layer, const float *dhp, const float *d
   const unsigned grid = (unsigned)(nblk < g_ncu_b ? nblk : g_ncu_b);
   resblock_bwd_conv_kernel<<<grid, 256, 0, st>>>(dy, dhp, dhin, ctx->w1b + (size_t)layer * 4 * 2 * C * C, L, logd, ntiles, (int)nblk);
   AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// The two backward weight images of this context (94 MB), built once per load: allocation + pack + a host synchronisation.  The
+// pointers the launch functions look at are published only after the pack has completed.
+int prepare_bwd_f32(ap_ctx *ctx, hipStream_t st) {
+  if (ctx->bwd_ready) return 0;
+  const size_t n1b = (size_t)ctx->NL * 4 * 2 * BC_ * BC_, n2 = (size_t)ctx->NL * 2 * BC_ * BC_;
+  if (!ctx->slab_b) AP_HIP(hipMalloc(&ctx->slab_b, (n1b + n2) * sizeof(float)));
+  ctx->w1b = (float *)ctx->slab_b;
+  ctx->w2t = ctx->w1b + n1b;
+  int rc = launch_pack_bwd(ctx, st);
+  if (rc == 0) {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize(prepare_backward)");
+  }
+  if (rc) {
+    (void)hipFree(ctx->slab_b);
+    ctx->slab_b = nullptr;
+    ctx->w1b = ctx->w2t = nullptr;
+    return rc;
+  }
+  ctx->bwd_ready = true;
   return 0;
 }
 

@@ -455,10 +455,9 @@ int launch_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *hin, const flo
     set_error("ap_resblock_bwd_bf16: built for AP_PREC_BF16 with res = skip = 256 channels and clips below 2^20 samples");
     return -22;
   }
-  if (!ctx->slab_bb) {                                           // first bf16 backward call of this context: its two own weight images
-    AP_HIP(hipMalloc(&ctx->slab_bb, (size_t)ctx->NL * (BW_W2T_ + BW_W1B_) * 2));
-    int rc = launch_pack_bwd_bf16(ctx, st);
-    if (rc) return rc;
+  if (!ctx->bwd_ready) {                                         // (launch functions allocate nothing: include/audiopure.h)
+    set_error("ap_resblock_bwd_bf16: the backward weight images are not built (ap_ctx_prepare_backward after every ap_ctx_load_wavenet)");
+    return -22;
   }
   const __bf16 *p = (const __bf16 *)ctx->slab_bb + (size_t)layer * (BW_W2T_ + BW_W1B_);
   const __bf16 *w1y = (const __bf16 *)ctx->w1p_bf + (size_t)layer * ((size_t)2 * QC_ * QC_ * 3);   // the forward's GEMM1 image
@@ -468,6 +467,24 @@ int launch_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *hin, const flo
                                                                      p, L, d, nt4);
   resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W2T_, L, d, nt);
   AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// This context's two bf16 backward weight images (47 MB): allocation + pack + a host synchronisation, published when complete.
+int prepare_bwd_bf16(ap_ctx *ctx, hipStream_t st) {
+  if (ctx->bwd_ready) return 0;
+  if (!ctx->slab_bb) AP_HIP(hipMalloc(&ctx->slab_bb, (size_t)ctx->NL * (BW_W2T_ + BW_W1B_) * 2));
+  int rc = launch_pack_bwd_bf16(ctx, st);
+  if (rc == 0) {
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize(prepare_backward)");
+  }
+  if (rc) {
+    (void)hipFree(ctx->slab_bb);
+    ctx->slab_bb = nullptr;
+    return rc;
+  }
+  ctx->bwd_ready = true;
   return 0;
 }
 

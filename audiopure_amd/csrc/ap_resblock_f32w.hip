@@ -547,7 +547,6 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
   }
 }
 
-static int g_ncu = 0;
 #ifdef AP_TOOLS
 static int g_ablate_f32w = 0;
 static int g_no_q16 = 0;                                        // ap_debug_f32w_q16(0): the 4-byte epilogue for every clip length (A/B)
@@ -565,12 +564,7 @@ bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L) {
 int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
                          int B, int L, hipStream_t st, float *aout) {
   if (!resblock_f32w_serves(ctx, B, L)) return 1;
-  if (g_ncu == 0) {
-    int dev = 0, n = 0;
-    AP_HIP(hipGetDevice(&dev));
-    AP_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    g_ncu = n > 0 ? n : 256;
-  }
+  const int g_ncu = device_cu_count();
   const int logd = layer % ctx->cfg.dilation_cycle;
   const long long d = 1ll << logd;
   const long long np = (L / (2 * d)) * d + ((L % (2 * d)) < d ? (L % (2 * d)) : d);      // pairs whose first output is inside the clip

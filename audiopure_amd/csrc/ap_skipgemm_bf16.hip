@@ -470,24 +470,17 @@ int launch_skipgemm_bf16(ap_ctx *ctx, int layer0, int nl, const void *gimg, floa
   if (nl < 1 || layer0 < 0 || layer0 + nl > ctx->NL || B < 1 || L < 1) { set_error("skip GEMM: layers [%d, %d) B=%d L=%d", layer0, layer0 + nl, B, L); return -22; }
   // (1024 L: a clip's fp32 skip rows -- the out-of-clip sentinel offset 0x80000000 of the epilogue must lie beyond them)
   if ((size_t)L * 1024 >= ((size_t)1 << 31)) { set_error("skip GEMM: clip too long (L * 1024 bytes of skip rows per clip must stay below 2^31)"); return -22; }
-  static int n_cu_of[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (n_cu_of[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-    n_cu_of[dev] = n;
-  }
+  const int n_cu = device_cu_count();
   const int ntiles = (L + SPT - 1) / SPT;
   const int nblk = B * ntiles;
-  const int grid = nblk < n_cu_of[dev] ? nblk : n_cu_of[dev];
+  const int grid = nblk < n_cu ? nblk : n_cu;
   const size_t n2 = (size_t)(C + S) * C;
   const unsigned wbytes = (unsigned)((size_t)ctx->NL * n2 * 2);
   const unsigned w2_off = (unsigned)((size_t)layer0 * n2 * 2);
   const float *b2 = ctx->b2 + (size_t)layer0 * (C + S) + C;
 #ifdef AP_TOOLS
   if (g_skipgemm_wide == 1) {
-    const int nt2 = (L + 255) / 256, nb2 = B * nt2, grid2 = nb2 < n_cu_of[dev] ? nb2 : n_cu_of[dev];
+    const int nt2 = (L + 255) / 256, nb2 = B * nt2, grid2 = nb2 < n_cu ? nb2 : n_cu;
     if (L % 4)
       skipgemm_bf16w_kernel<true><<<(unsigned)grid2, 512, 0, st>>>(gimg, skip, ctx->w2p_bf, wbytes, w2_off, (unsigned)(n2 * 2), b2, (unsigned)(C + S), B, L, nl,
                                                                  accumulate, nt2, nb2);

@@ -97,7 +97,7 @@ class NativeEngine:
         # layer of a group keeps a [B][L][C] bf16 image (8.2 MB per clip-second): 36 layers = 295 MB per clip on top of the
         # 49 MB of activations (B = 512: 176 GB of the 288) -- where that does not fit, `chunks` walks the batch in smaller calls.  0 = the fused block.
         self.skip_group = min(self.SKIP_GROUP, cfg["num_res_layers"])
-        self._ds_ok = (precision == N.AP_PREC_BF16 and cfg["res_channels"] == 256 and cfg["skip_channels"] == 256)
+        self._ds_ok = (precision in (N.AP_PREC_BF16, N.AP_PREC_BF16_STORE) and cfg["res_channels"] == 256 and cfg["skip_channels"] == 256)
 
     def __del__(self):
         try:
@@ -200,10 +200,15 @@ class WaveNet_Speech_Commands(nn.Module):
         F(2,3) minimal-filtering form (include/audiopure.h: ap_ctx_set_f32_form), "f32d" keeps the direct form.  "f32s": fp32 operands split exactly into three
         bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results (held to the fp32
         tolerances and, on adversarial operands, to twice the direct fp32 kernel's error against fp64), ~1.3x the F(2,3) form's rate.
-        "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  All but "f32" need
-        res_channels = 256."""
-        prec = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "f32d": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
-                "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT}[mode]
+        "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  "bf16s": the same arithmetic with the
+        residual stream stored as bf16 between layers (SURVEY.md 8d "bf16 MFMA, bf16 storage"; one more rounding per layer,
+        forward only).  All but "f32" need res_channels = 256."""
+        modes = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "f32d": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
+                 "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "bf16s": N.AP_PREC_BF16_STORE,
+                 "bf16_store": N.AP_PREC_BF16_STORE}
+        if mode not in modes:
+            raise ValueError(f"set_precision: unknown mode {mode!r} (one of {sorted(modes)}; 'f32h' was removed in round 5)")
+        prec = modes[mode]
         self._f32_form = 0 if mode == "f32d" else 1
         if prec != self._precision:
             self._precision = prec

@@ -40,6 +40,7 @@ class EpsGrad:
     def __init__(self, net):
         self.net = net
         self._key = None
+        self._gimg = None               # bf16 mode: the group's gate images of forward_save, one buffer reused by every link
         self.fused_bf16 = True          # tools/check_bwd_bf16.py turns it off to time / compare the composed fp32 backward in bf16 mode
 
     # ---- weights ---------------------------------------------------------------------------------------
@@ -52,6 +53,13 @@ class EpsGrad:
         lib, dev = eng.lib, next(net.parameters()).device
         C_, S_, NL = eng.cfg.res_channels, eng.cfg.skip_channels, eng.cfg.num_res_layers
         cyc = eng.cfg.dilation_cycle
+        if net._precision == N.AP_PREC_BF16_STORE:
+            raise N.NativeError("set_precision('bf16s') (AP_PREC_BF16_STORE) is forward-only: no backward is built for the bf16 residual "
+                                "stream; use 'bf16' or 'f32' for the differentiable purifier")
+        if C_ == 256 and S_ == 256 and net._precision in (N.AP_PREC_F32, N.AP_PREC_BF16):
+            # the fused backward kernels' own weight images: built here, once per load, outside any stream capture (the launch
+            # functions allocate nothing: include/audiopure.h, ap_ctx_prepare_backward)
+            N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()), "ap_ctx_prepare_backward")
 
         def folded(which, layer, n):
             t = torch.empty(n, device=dev, dtype=torch.float32)
@@ -99,14 +107,26 @@ class EpsGrad:
 
     def saved_bytes(self, x: torch.Tensor, acts: bool = True) -> int:
         """Bytes ``forward_save(x, ., acts)`` keeps, computed without allocating: NL + 1 layer inputs [B][C][L], the skip sum,
-        the FiLM vectors and -- ``acts`` in fp32 arithmetic -- NL pre-gate tensors [B][2C][L]."""
+        the FiLM vectors and -- ``acts`` in fp32 arithmetic -- NL pre-gate tensors [B][2C][L]; in bf16 mode also the gate-image
+        buffer of the deferred-skip forward while this object does not hold one of that size yet (it is allocated once and
+        reused by every link, so only the first link is charged for it)."""
         eng = self._prepare()
         B, _, L = x.shape
         C_, S_, NL = self.C, self.S, self.NL
         n = (NL + 1) * B * C_ * L + B * S_ * L + NL * C_ + eng.cfg.embed_dim_out
         if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256):
             n += NL * B * 2 * C_ * L
-        return 4 * n
+        extra = 0
+        G = self._group(eng)
+        if G > 0:
+            need = min(G, NL) * B * L * C_ * 2
+            if self._gimg is None or self._gimg.numel() * 2 < need or self._gimg.device != x.device:
+                extra = need
+        return 4 * n + extra
+
+    def _group(self, eng) -> int:
+        """Layers per skip GEMM of forward_save's deferred-skip form (bf16 mode; 0: the fused block per layer)."""
+        return int(eng.skip_group or 0) if getattr(eng, "_ds_ok", False) and self.net._precision == N.AP_PREC_BF16 else 0
 
     def eps_only(self, x: torch.Tensor, step: float):
         """The plain fused forward (``ap_eps_fwd``): what the chain's forward pass calls -- nothing is kept."""
@@ -128,11 +148,17 @@ class EpsGrad:
         skip = torch.empty((B, S_, L), device=dev)
         pre = torch.empty((NL, B, 2 * C_, L), device=dev) if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256) else None
         N.check(lib.ap_init_conv(eng.ctx, N.ptr(x), N.ptr(hs[0]), B, L, N.stream()), "ap_init_conv")
-        G = int(eng.skip_group or 0) if getattr(eng, "_ds_ok", False) and self.net._precision == N.AP_PREC_BF16 else 0
+        G = self._group(eng)
         if G > 0:
             # bf16 mode, the deferred-skip form the chain's own forward runs (ap_resblock_fwd_gate + one ap_skip_gemm per group of G
-            # layers: same grouping, so eps equals ap_eps_fwd's bit for bit); the last layer's h' is not computed (nobody reads it)
-            gimg = torch.empty((min(G, NL), B, L, C_), device=dev, dtype=torch.bfloat16)
+            # layers: same grouping, so eps equals ap_eps_fwd's bit for bit); the last layer's h' is not computed (nobody reads it:
+            # hs[NL] stays unwritten and backward() starts from dh = 0).  The gate images live in ONE buffer held by this object
+            # and reused by every link (295 MB per clip-second at G = 36; saved_bytes charges it to the chain's budget once).
+            need = min(G, NL) * B * L * C_
+            if self._gimg is None or self._gimg.numel() < need or self._gimg.device != dev:
+                self._gimg = None
+                self._gimg = torch.empty(need, device=dev, dtype=torch.bfloat16)
+            gimg = self._gimg[:need].view(min(G, NL), B, L, C_)
             for n0 in range(0, NL, G):
                 nl = min(G, NL - n0)
                 for n in range(n0, n0 + nl):

@@ -12,11 +12,11 @@
  *    negative errno-style code and never throws; ap_last_error() gives the text.
  *  - every `*_dev` / float* tensor argument is a DEVICE pointer owned by the
  *    caller (e.g. the PyTorch caching allocator); the library allocates device
- *    memory only inside ap_ctx_load_wavenet / ap_m5_create.
+ *    memory only inside ap_ctx_load_wavenet / ap_ctx_prepare_backward / ap_m5_create.
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
  *    All work is enqueued asynchronously on it; nothing synchronises the host
- *    (ap_ctx_load_wavenet / ap_m5_create excepted), so every launch function is
- *    hipGraph-capturable.
+ *    (ap_ctx_load_wavenet / ap_ctx_prepare_backward / ap_m5_create excepted), so every
+ *    launch function is hipGraph-capturable.
  *  - tensors are fp32, layout [B][C][L] row-major with the sample axis contiguous,
  *    exactly the reference's `[B,1,16000]` / `[B,C,L]` tensors.
  *  - noise: `z` arguments may be NULL; then N(0,1) samples come from the library's
@@ -49,7 +49,7 @@ enum {
   AP_PREC_BF16 = 1,  /* bf16 operands (RNE), fp32 accumulate; activations stay fp32 in HBM.  Built for the shipped
                         configuration only: res_channels == skip_channels == 256 (any dilation of a power-of-two cycle,
                         any clip length); other shapes return -EINVAL at the first launch (ap_last_error says which) */
-  AP_PREC_F32_SPLIT = 2  /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
+  AP_PREC_F32_SPLIT = 2, /* fp32 operands split exactly into three bf16 parts, the six partial products >= 2^-16 of
                             each product on v_mfma_f32_32x32x16_bf16, fp32 accumulate: fp32-class results (dropped
                             terms < 2^-23 of a product) at 6/16 of the fp32 matrix instruction's time; C = 256.  Held to the
                             fp32 kernels' tolerances, and on adversarial operands (cancellation, a 2^40 dynamic range)
@@ -57,6 +57,11 @@ enum {
                             (tests/test_gpu_parity.py::test_fp32_class_modes_bound_their_error_on_adversarial_operands) */
   /* (value 3, AP_PREC_F32_SPLIT_F16 -- two fp16 parts per operand -- was removed in round 5: fp16's exponent range loses
      channels a 2^20 dynamic range apart outright, profiles/r5_fp32_class_adversarial_error.txt) */
+  AP_PREC_BF16_STORE = 4  /* AP_PREC_BF16's arithmetic with the residual stream kept in HBM as bf16 (third precision
+                             row): each layer hands the next one u = bf16(h' + part_t of that layer) -- the dilated conv's operand
+                             and, by the reference's in-place alias (WaveNet.py:77,84), the value the residual carries -- as an
+                             image [B][C/32][L][32] (ap_resblock_fwd_u); skip stays fp32 (deferred-skip form).  One more rounding
+                             per layer than AP_PREC_BF16 (the residual sees bf16(u) instead of fp32 u).  Forward only.  C = 256. */
 };
 
 /* configs/config.json "wavenet_config" + "diffusion_config" (reference: configs/config.json:2-17) */
@@ -193,6 +198,18 @@ int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, fl
                  int B, int L, void *stream);
 int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group);
 
+/* AP_PREC_BF16_STORE block interface (ap_resblock_bf16u.hip).  The u image of a layer: [B][C / 32][L][32] bf16 -- a sample's 32
+ * channels of one 32-channel chunk are one 64-byte row, and inside a row position p holds the chunk's channel (p with bits 2 and 3
+ * swapped: the register order of a 32 x 32 MFMA accumulator tile, so the epilogue stores straight from its accumulators).
+ *   ap_init_conv_u:    u_0 = bf16(ReLU(W0 x + b0) + part_t of layer 0)        (WaveNet.py:147,168 then :82-84)
+ *   ap_resblock_fwd_u: y = DilConv(u_in) + b;  g = tanh . sigmoid;  h' = (u_in + W_res bf16(g) + b_res) sqrt(1/2)   (WaveNet.py:87-97);
+ *                      u_out = bf16(h' + part_t_next) (part_t_next: [C] of layer + 1), g_image [B][L][C] bf16 for ap_skip_gemm.
+ *                      u_out NULL (the net's last layer, whose h' nobody reads: WaveNet.py:131-135): res_conv and the store are left out.
+ * ap_resblock_fwd / _gate / _save return -22 in this mode (their h tensors are fp32).  ap_eps_fwd / ap_purify_* run the whole sweep. */
+int ap_init_conv_u(ap_ctx *ctx, const float *x, const float *part_t_layer0, void *u_out, int B, int L, void *stream);
+int ap_resblock_fwd_u(ap_ctx *ctx, int layer, const void *u_in, const float *part_t_next, void *u_out, void *g_image, int B, int L,
+                      void *stream);
+
 /* AP_PREC_F32 arithmetic form of the dilated conv (WaveNet.py:87).  1 (default where built: res = skip = 256 channels): the
  * F(2,3) minimal-filtering form over the dilation pair -- outputs t and t + d share their four taps, so the pair costs four
  * [2C x C] products instead of six (block: 12.58 GFLOP per clip instead of 16.78) on the exact-fp32 matrix instruction;
@@ -222,6 +239,11 @@ int ap_resblock_fwd_save(ap_ctx *ctx, int layer, const float *h_in, const float 
  * frozen (no weight gradients).  AP_PREC_F32, res = skip = 256 channels; ap_resblock_bwd_available says whether a shape is served. */
 int ap_resblock_bwd(ap_ctx *ctx, int layer, const float *dh_out, const float *dskip, const float *pre_gate, float *dy_scratch,
                     float *dh_in, int B, int L, void *stream);
+/* The backward kernels read their own weight images (fp32: 94 MB, bf16: 47 MB at the shipped shape).  ap_ctx_prepare_backward
+ * allocates and packs them for the context's precision and synchronises the host -- like ap_ctx_load_wavenet it is NOT a launch
+ * function (call it outside stream capture, once after every ap_ctx_load_wavenet; a second call is a no-op).  ap_resblock_bwd /
+ * ap_resblock_bwd_bf16 return -22 until it has been called: they allocate nothing and stay hipGraph-capturable. */
+int ap_ctx_prepare_backward(ap_ctx *ctx, void *stream);
 int ap_resblock_bwd_available(ap_ctx *ctx, int B, int L);
 /* The same gradient in AP_PREC_BF16 (bf16 MFMA operands, fp32 accumulate), from the layer INPUT instead of kept pre-gate activations --
  * on the bf16 matrix pipe the dilated conv is cheaper to recompute than a [B][2C][L] fp32 store per layer is to write:

@@ -125,19 +125,25 @@ def winograd_dilated_conv(u: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, 
 
 
 def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor, bf16_operands: bool = False,
-                   winograd: bool = False):
+                   winograd: bool = False, bf16_store: bool = False):
     """One ``Residual_block.forward`` (WaveNet.py:75-97).
 
     NB the reference's ``h += part_t`` aliases the block input (``h = x`` at :77,
     in-place add at :84), so the residual branch is ``(x + part_t + res) * sqrt(.5)``.
     ``bf16_operands`` emulates the bf16 mode of the HIP path: both GEMMs see bf16-rounded operands
     (u, W_dil, g, W_res, W_skip), products/accumulation and everything else stay fp32.
+    ``bf16_store`` (implies ``bf16_operands``) emulates AP_PREC_BF16_STORE ("bf16 MFMA, bf16 storage"): what a layer
+    hands to the next one through memory is u = bf16(h + part_t) -- ONE rounding per layer -- and because of the alias above that
+    same rounded u is what the residual carries: ``(bf16(u) + res) * sqrt(.5)``.  The returned h' stays fp32 (the next block rounds
+    it together with its own part_t); skip stays fp32.
     """
     p = f"residual_layer.residual_blocks.{n}"
-    q = _bf16 if bf16_operands else (lambda t: t)
+    q = _bf16 if (bf16_operands or bf16_store) else (lambda t: t)
     B, C, L = x.shape
     part_t = F.linear(emb, w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).view(B, C, 1)    # :82-83
     u = x + part_t                                                                       # :84 (alias!)
+    if bf16_store:
+        u = _bf16(u)
     if winograd:
         h = winograd_dilated_conv(u, w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"], dilation)
     else:
@@ -150,7 +156,7 @@ def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.T
 
 
 def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict | None = None,
-            bf16_operands: bool = False, winograd: bool = False) -> torch.Tensor:
+            bf16_operands: bool = False, winograd: bool = False, bf16_store: bool = False) -> torch.Tensor:
     """``WaveNet_Speech_Commands.forward((audio, diffusion_steps))`` (WaveNet.py:164-172).
 
     w: folded weights (``fold_state_dict``); x: [B,1,L]; steps: float [B,1].
@@ -164,13 +170,13 @@ def eps_net(w: dict, cfg: dict, x: torch.Tensor, steps: torch.Tensor, taps: dict
     emb = _swish(F.linear(emb, w["residual_layer.fc_t2.weight"], w["residual_layer.fc_t2.bias"]))   # :126
     skip = 0
     for n in range(N):                                                                   # :131-133
-        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb, bf16_operands, winograd)
+        h, skip_n = residual_block(w, n, 2 ** (n % cyc), h, emb, bf16_operands, winograd, bf16_store)
         skip = skip + skip_n
         if taps is not None:
             taps[f"h{n}"] = h
             taps[f"skip{n}"] = skip
     y = skip * math.sqrt(1.0 / N)                                                        # :135
-    q = _bf16 if bf16_operands else (lambda t: t)      # bf16 mode: final_conv's S -> S 1x1 runs on the bf16 pipe as well
+    q = _bf16 if (bf16_operands or bf16_store) else (lambda t: t)      # bf16 modes: final_conv's S -> S 1x1 runs on the bf16 pipe as well
     y = F.conv1d(q(y), q(w["final_conv.0.conv.weight"]), w["final_conv.0.conv.bias"])    # :160
     y = F.relu(y)                                                                        # :161
     return F.conv1d(y, w["final_conv.2.conv.weight"], w["final_conv.2.conv.bias"])       # :162
@@ -188,22 +194,22 @@ def q_sample(dh: dict, x0: torch.Tensor, t_star: int, z: torch.Tensor) -> torch.
     return torch.sqrt(ab) * x0 + torch.sqrt(1 - ab) * z                                  # :67
 
 
-def ddpm_coefficients(w, cfg, dh, x, t: int, bf16_operands: bool = False, winograd: bool = False):
-    eps = eps_net(w, cfg, x, _steps(x.shape[0], t), bf16_operands=bf16_operands, winograd=winograd)   # :157-158
+def ddpm_coefficients(w, cfg, dh, x, t: int, bf16_operands: bool = False, winograd: bool = False, bf16_store: bool = False):
+    eps = eps_net(w, cfg, x, _steps(x.shape[0], t), bf16_operands=bf16_operands, winograd=winograd, bf16_store=bf16_store)   # :157-158
     A, Ab = dh["Alpha"], dh["Alpha_bar"]
     mu = (x - (1 - A[t]) / torch.sqrt(1 - Ab[t]) * eps) / torch.sqrt(A[t])               # :159
     return eps, mu, dh["Sigma"][t]                                                       # :160
 
 
 def ddpm_purify(w, cfg, dh, x0: torch.Tensor, t_star: int, noises: list, bf16_operands: bool = False,
-                winograd: bool = False) -> torch.Tensor:
+                winograd: bool = False, bf16_store: bool = False) -> torch.Tensor:
     """``DiffWave.forward`` with injected noise: noises[0] = q-sample z, noises[k] = k-th reverse draw.
     ``bf16_operands``: every eps-evaluation of the chain emulates the AP_PREC_BF16 mode (see ``residual_block``)."""
     with torch.no_grad():
         x = q_sample(dh, x0, t_star, noises[0])
         k = 1
         for t in range(t_star - 1, -1, -1):                                              # :95
-            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t, bf16_operands, winograd)
+            _, mu, sigma = ddpm_coefficients(w, cfg, dh, x, t, bf16_operands, winograd, bf16_store)
             if t > 0:
                 x = mu + sigma * noises[k]                                               # :100
                 k += 1
@@ -282,7 +288,7 @@ def sde_tables(T: int = 200, beta_0: float = 0.0001, beta_T: float = 0.02) -> di
             "sqrt_1m_alphas_cumprod": torch.sqrt(1.0 - ac)}
 
 
-def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int, bf16_operands: bool = False):
+def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int, bf16_operands: bool = False, bf16_store: bool = False):
     """Drift f and diffusion g of the REVERSE SDE in torchsde time at discrete index k
     (= ``RevVPSDE.f`` / ``.g`` with ``disc_steps = k``; :73-134)."""
     N = tb["N"]
@@ -290,7 +296,7 @@ def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int, bf16_operands: bool = Fal
     drift = -0.5 * beta_t * x                                                            # :79
     diffusion = torch.sqrt(beta_t)                                                       # :80
     eps = eps_net(w, cfg, x.view(x.shape[0], 1, -1), _steps(x.shape[0], k),
-                  bf16_operands=bf16_operands).view(x.shape[0], -1)                      # :95-97
+                  bf16_operands=bf16_operands, bf16_store=bf16_store).view(x.shape[0], -1)   # :95-97
     score = -eps / tb["sqrt_1m_alphas_cumprod"][k]                                       # :99
     drift = drift - diffusion ** 2 * score                                               # :104
     if k > 0:
@@ -301,7 +307,7 @@ def sde_f_g(w, cfg, tb: dict, x: torch.Tensor, k: int, bf16_operands: bool = Fal
 
 
 def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list, q_level: int | None = None,
-               bf16_operands: bool = False) -> torch.Tensor:
+               bf16_operands: bool = False, bf16_store: bool = False) -> torch.Tensor:
     """``RevDiffWave.audio_editing_sample`` (sample_step = 1) with torchsde's Euler scheme
     ``y <- y + f h + g sqrt(h) z`` restated (torchsde 0.2.5, un-vendored: parity unpinned for
     the loop itself).  h = 1/N; steps k = t*-1 ... 0: exactly t* eps-evaluations (the reference's
@@ -316,7 +322,7 @@ def sde_purify(w, cfg, tb: dict, x0: torch.Tensor, t_star: int, noises: list, q_
         y = x.view(x.shape[0], -1)
         h = 1.0 / N
         for i, k in enumerate(range(t_star - 1, -1, -1)):
-            f, g = sde_f_g(w, cfg, tb, y, k, bf16_operands)
+            f, g = sde_f_g(w, cfg, tb, y, k, bf16_operands, bf16_store)
             y = y + f * h + g * math.sqrt(h) * noises[1 + i].view(y.shape)
         return y.view(x.shape)
 

@@ -1,0 +1,312 @@
+"""AP_PREC_BF16_STORE (`set_precision("bf16s")`): SURVEY.md 8(d)'s third precision row -- bf16 MFMA operands, fp32 accumulate, the
+residual stream stored as bf16 between layers (ap_resblock_bf16u.hip) -- against the oracle's emulation of exactly that
+(`oracle/diffwave_oracle.py`: ``bf16_store=True`` rounds u = h + part_t once per layer, WaveNet.py:77,84 alias kept) and
+against the reference's fp32 golden vectors.
+
+Stated tolerances (all relative to the reference tensor's largest magnitude):
+  * block, stored image u' : 6e-3 = 2e-3 (AP_PREC_BF16's own h' tolerance: rounding-boundary flips of g) + 2^-8 (one bf16 ulp of the
+    stored value where the two sides round a near-tie differently); the MEAN deviation must stay under 3e-4;
+  * block, skip (through ap_skip_gemm): 4e-3 (AP_PREC_BF16's);
+  * one eps-evaluation: 1e-2 (AP_PREC_BF16's); 5-step chain vs the bf16-store chain oracle 5e-3 (AP_PREC_BF16's), vs the
+    reference's fp32 vector 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from audiopure_amd import synth
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def dh():
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.util import calc_diffusion_hyperparams
+    return calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
+
+
+def _oracle():
+    from oracle import diffwave_oracle as O
+    return O
+
+
+def _net(cfg, dev, seed=0, mode="bf16s"):
+    from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNet_Speech_Commands
+    sd = synth.wavenet_state_dict(cfg, seed)
+    net = WaveNet_Speech_Commands(**cfg)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return net.to(dev).set_precision(mode), sd
+
+
+def _swap23(p):
+    return (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
+
+
+PERM = torch.tensor([_swap23(p) for p in range(32)])             # position p of an image row holds channel PERM[p] of its chunk (an involution)
+
+
+def to_uimg(u):
+    """[B][C][L] values -> the u image [B][C/32][L][32] bf16 of include/audiopure.h (ap_resblock_fwd_u)."""
+    B, C_, L = u.shape
+    x = u.reshape(B, C_ // 32, 32, L)[:, :, PERM.to(u.device), :]
+    return x.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+
+
+def from_uimg(img):
+    B, NC, L, _ = img.shape
+    x = img.float().permute(0, 1, 3, 2)[:, :, PERM.to(img.device), :]
+    return x.reshape(B, NC * 32, L).contiguous()
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _ulp_bf16(t):
+    """Spacing of bf16 numbers at |t| (8 significant bits)."""
+    a = t.abs().clamp_min(1e-30)
+    return torch.exp2(torch.floor(torch.log2(a)) - 7)
+
+
+def test_image_helpers_round_trip():
+    u = torch.arange(2 * 64 * 5, dtype=torch.float32).reshape(2, 64, 5)
+    img = to_uimg(u / 4096.0)                                     # (bf16-exact values)
+    assert img.shape == (2, 2, 5, 32)
+    assert torch.equal(from_uimg(img), _bf16(u / 4096.0))
+    assert float(img[0, 0, 0, 4]) == float(_bf16(u / 4096.0)[0, 8, 0])     # position 4 = channel 8 (bits 2, 3 swapped)
+
+
+@pytest.mark.parametrize("B,L", [(2, 1000), (3, 16000), (1, 5)])
+def test_init_conv_image_is_relu_conv_plus_film_rounded_once(dev, B, L):
+    """ap_init_conv_u: u_0 = bf16(ReLU(W0 x + b0) + part_t of layer 0) (WaveNet.py:147,168 then :82-84) in image layout."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    x = torch.from_numpy(synth.waveforms(B, L, seed=3))
+    pt = torch.from_numpy(synth.uniform("pt0", (256,), 1, -1.0, 1.0))
+    with torch.no_grad():
+        h0 = torch.nn.functional.conv1d(x, w["init_conv.0.conv.weight"], w["init_conv.0.conv.bias"]).clamp_min(0)
+        ref = _bf16(h0 + pt.view(1, -1, 1))
+    img = torch.empty((B, 8, L, 32), dtype=torch.bfloat16, device=dev)
+    xd, ptd = x.to(dev), pt.to(dev)
+    N.check(eng.lib.ap_init_conv_u(eng.ctx, N.ptr(xd), N.ptr(ptd), img.data_ptr(), B, L, N.stream()))
+    got = from_uimg(img).cpu()
+    d = (got - ref).abs()
+    assert (d <= _ulp_bf16(ref)).all()                            # fma vs mul + add before the rounding: at most one ulp, rarely
+    assert (d == 0).float().mean() > 0.995
+
+
+# every dilation of a cycle (d = 1 .. 2048, incl. d >= L), single-tile clips, ragged last tiles, clip lengths that are not a multiple of four
+@pytest.mark.parametrize("L,layer", [(2048, 0), (1500, 5), (4133, 10), (130, 3), (2048, 1), (2048, 2), (1536, 3), (2048, 4), (1920, 5),
+                                     (2048, 6), (2048, 7), (4096, 9), (4096, 10), (1024, 8), (16000, 10), (128, 0), (64, 1),
+                                     (132, 5), (4, 2), (1, 0), (1001, 0), (1002, 1), (1003, 4), (2049, 8), (16001, 10)])
+def test_bf16_store_block_matches_the_bf16_store_oracle(dev, L, layer):
+    """One Residual_block.forward (WaveNet.py:75-97) in AP_PREC_BF16_STORE: the stored image u' = bf16(h' + part_t of the next
+    layer) and the skip contribution (via the gate image and ap_skip_gemm) against the oracle block with bf16_store=True."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    B, C_ = 2, 256
+    h = torch.from_numpy(synth.uniform(f"hb/{L}", (B, C_, L), 1, -1.5, 1.5))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    with torch.no_grad():
+        def part(n):
+            p = f"residual_layer.residual_blocks.{n}"
+            return torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        pt, ptn = part(layer), part(layer + 1)
+        h_q, s_q = O.residual_block(w, layer, 2 ** (layer % 12), h.clone(), emb, bf16_store=True)
+        u_ref = _bf16(h_q + ptn.view(1, -1, 1))
+        u_in = _bf16(h + pt.view(1, -1, 1))
+    uin = to_uimg(u_in.to(dev))
+    uout = torch.zeros_like(uin)
+    gimg = torch.empty((B, L, C_), dtype=torch.bfloat16, device=dev)
+    ptn_d = ptn.to(dev)
+    N.check(eng.lib.ap_resblock_fwd_u(eng.ctx, layer, uin.data_ptr(), N.ptr(ptn_d), uout.data_ptr(), gimg.data_ptr(), B, L, N.stream()))
+    got = from_uimg(uout).cpu()
+    m = float(u_ref.abs().max())
+    d = (got - u_ref).abs()
+    assert float(d.max()) < 6e-3 * m, (float(d.max()) / m)
+    assert float(d.mean()) < 3e-4 * m
+    sk = torch.full((B, C_, L), 3.0, device=dev)
+    N.check(eng.lib.ap_skip_gemm(eng.ctx, layer, 1, gimg.data_ptr(), N.ptr(sk), 0, B, L, N.stream()))
+    assert rel_err(sk.cpu().numpy(), s_q.numpy()) < 4e-3
+    # u_out = NULL (the net's last layer): the same g image, nothing else written
+    g2 = torch.zeros_like(gimg)
+    N.check(eng.lib.ap_resblock_fwd_u(eng.ctx, layer, uin.data_ptr(), None, None, g2.data_ptr(), B, L, N.stream()))
+    assert torch.equal(g2.view(torch.int16), gimg.view(torch.int16))
+    # run-to-run bit identity
+    uout2 = torch.zeros_like(uin)
+    N.check(eng.lib.ap_resblock_fwd_u(eng.ctx, layer, uin.data_ptr(), N.ptr(ptn_d), uout2.data_ptr(), g2.data_ptr(), B, L, N.stream()))
+    assert torch.equal(uout2.view(torch.int16), uout.view(torch.int16))
+
+
+@pytest.mark.parametrize("L,layer", [(2048, 0), (4096, 7), (16000, 10), (1003, 4)])
+def test_bf16_store_block_agrees_with_the_bf16_block_on_bf16_inputs(dev, L, layer):
+    """Kernel against kernel: AP_PREC_BF16's block fed h = u (bf16-exact values) and part_t = 0 sees the same GEMM operands and the
+    same residual as AP_PREC_BF16_STORE's block fed the image of u; rounding its fp32 h' + part_t(next) to bf16 must give the stored
+    image except where the two MFMA summation orders (the image's K order is permuted inside a chunk) leave a value on different
+    sides of a rounding boundary: >= 99.5 % of the elements bit-equal, the rest one bf16 ulp away (a flipped g element upstream can
+    move a handful further: <= 2e-3 of max, AP_PREC_BF16's own h' tolerance)."""
+    from audiopure_amd import _native as N
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net_u, _ = _net(cfg, dev, seed=3)
+    net_b, _ = _net(cfg, dev, seed=3, mode="bf16")
+    eu, eb = net_u.engine(), net_b.engine()
+    B, C_ = 2, 256
+    u = _bf16(torch.from_numpy(synth.uniform(f"ub/{L}", (B, C_, L), 1, -1.5, 1.5))).to(dev)
+    ptn = torch.from_numpy(synth.uniform("ptn", (C_,), 1, -1.0, 1.0)).to(dev)
+    zero = torch.zeros(C_, device=dev)
+    uin = to_uimg(u)
+    uout = torch.zeros_like(uin)
+    g_u = torch.empty((B, L, C_), dtype=torch.bfloat16, device=dev)
+    N.check(eu.lib.ap_resblock_fwd_u(eu.ctx, layer, uin.data_ptr(), N.ptr(ptn), uout.data_ptr(), g_u.data_ptr(), B, L, N.stream()))
+    hout = torch.empty_like(u)
+    g_b = torch.empty_like(g_u)
+    N.check(eb.lib.ap_resblock_fwd_gate(eb.ctx, layer, N.ptr(u), N.ptr(zero), N.ptr(hout), g_b.data_ptr(), B, L, N.stream()))
+    ref = _bf16(hout + ptn.view(1, -1, 1))
+    got = from_uimg(uout)
+    same = (got == ref).float().mean().item()
+    d = (got - ref).abs()
+    far = (d > _ulp_bf16(ref)).float().mean().item()
+    gsame = (g_u.view(torch.int16) == g_b.view(torch.int16)).float().mean().item()
+    print(f"L={L} layer={layer}: u' bit-equal {same:.5f}, beyond one ulp {far:.2e}, g bit-equal {gsame:.5f}")
+    assert same > 0.995 and gsame > 0.995
+    assert far < 1e-3
+    assert float(d.max()) < 2e-3 * float(ref.abs().max()) + float(_ulp_bf16(ref).max())
+
+
+@pytest.mark.parametrize("L", [16000, 23457, 5003, 1001, 130])
+def test_bf16_store_eps_meets_the_bf16_store_oracle(dev, L):
+    """One eps-evaluation of a 12-layer, 256-channel net (every dilation of the cycle; clip lengths incl. ones that are not a multiple
+    of four: kws_adaptive_attack_eval.py:178) against the oracle network with the same roundings: 1e-2 of max|eps|."""
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=5)
+    w = O.fold_state_dict(sd)
+    x = torch.from_numpy(synth.waveforms(2, L, seed=L))
+    got = net.eps(x.to(dev), 3.0).cpu()
+    with torch.no_grad():
+        ref = O.eps_net(w, cfg, x, 3.0 * torch.ones(2, 1), bf16_store=True)
+        ref_f = O.eps_net(w, cfg, x, 3.0 * torch.ones(2, 1))
+    e_q, e_f = rel_err(got.numpy(), ref.numpy()), rel_err(got.numpy(), ref_f.numpy())
+    print(f"bf16s eps L={L}: vs bf16-store oracle {e_q:.2e}, vs fp32 oracle {e_f:.2e}")
+    assert e_q < 1e-2
+    assert e_f < 3e-2
+
+
+def test_bf16_store_eps_does_not_depend_on_the_skip_group(dev):
+    """The grouping of the deferred skip GEMM changes the fp32 summation order of skip only (include/audiopure.h)."""
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, _ = _net(cfg, dev, seed=5)
+    eng = net.engine()
+    x = torch.from_numpy(synth.waveforms(2, 3000, seed=9)).to(dev)
+    outs = []
+    try:
+        for G in (12, 5, 1):
+            eng.skip_group = G
+            outs.append(net.eps(x, 2.0).cpu())
+    finally:
+        eng.skip_group = min(eng.SKIP_GROUP, 12)
+    for o in outs[1:]:
+        assert rel_err(o.numpy(), outs[0].numpy()) < 2e-3
+
+
+TOL_CHAIN_Q = 5e-3            # vs the bf16-store chain oracle
+TOL_CHAIN_F = 2e-3            # vs the reference's fp32 vector
+
+
+def test_bf16_store_full_chain_matches_oracle_chain_and_the_fp32_reference(golden, dev, dh):
+    """BASELINE configs[1]'s workload at B = 2 in AP_PREC_BF16_STORE: shipped config, DDPM n = 5 (diffwave_ddpm.py:49-104) + M5,
+    against the chain oracle with the same roundings, against the reference's fp32 golden vector, and the classifier's decision
+    against the reference's (argmax agreement reported and asserted)."""
+    from audiopure_amd.audio_models.M5.M5Net import M5
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    O = _oracle()
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, sd = _net(cfg, dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=5)
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234))
+    z = [torch.from_numpy(synth.noise(d, 2, 16000, seed=1234)) for d in range(5)]
+    dw.set_noise_source(list(z))
+    xp = dw(x0.to(dev))
+    ref_q = O.ddpm_purify(O.fold_state_dict(sd), cfg, O.diffusion_hyperparams(**synth.DIFFUSION_CONFIG), x0, 5, z, bf16_store=True)
+    err_q = rel_err(xp.cpu().numpy(), ref_q.numpy())
+    err_f = rel_err(xp.cpu().numpy(), golden["full/ddpm_n5/x"])
+    m5 = M5(n_input=1, n_output=10)
+    m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
+    lp = m5.to(dev).eval()(xp).cpu().numpy()
+    lp_ref = golden["full/ddpm_n5/m5_logprobs"]
+    agree = float((lp.argmax(1) == lp_ref.argmax(1)).mean())
+    print(f"bf16s chain: vs bf16-store oracle {err_q:.2e}, vs fp32 reference {err_f:.2e}; M5 log-prob max dev "
+          f"{np.abs(lp - lp_ref).max():.2e}, argmax agreement {agree:.2f}")
+    assert err_q < TOL_CHAIN_Q
+    assert err_f < TOL_CHAIN_F
+    assert agree == 1.0
+    assert np.abs(lp - lp_ref).max() < 5e-2
+
+
+def test_bf16_store_full_batch_equals_small_batches_bit_for_bit(dev, dh):
+    """B = 512 (BASELINE configs[1]'s batch): clips 0-1 and 510-511 equal the same clips purified in batches of two, bit for bit --
+    a clip's result does not depend on the batch it travels in (fixed skip group, Philox keyed on the global utterance index)."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, _ = _net(cfg, dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    x = torch.from_numpy(synth.waveforms(512, 16000, seed=78)).to(dev)
+    dw.set_noise_source(("philox", 17, 0))
+    big = dw(x)
+    assert big.shape == x.shape and torch.isfinite(big).all()
+    dw.set_noise_source(("philox", 17, 0))
+    assert torch.equal(dw(x[:2]), big[:2])
+    dw.set_noise_source(("philox", 17, 510))
+    assert torch.equal(dw(x[510:]), big[510:])
+
+
+def test_bf16_store_is_forward_only_and_says_so(dev, dh):
+    """No backward is built for the bf16 residual stream: asking for a gradient raises (never a silently detached result), and the
+    fp32-tensor block entry points refuse the mode."""
+    from audiopure_amd import _native as N
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, _ = _net(cfg, dev, seed=5)
+    x = torch.from_numpy(synth.waveforms(1, 512, seed=2)).to(dev).requires_grad_(True)
+    with pytest.raises(N.NativeError, match="forward-only"):
+        net.eps(x, 1.0)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
+    with pytest.raises(N.NativeError, match="forward-only"):
+        dw.one_shot_denoise(x)                                   # differentiable in the reference (diffwave_ddpm.py:174-182); forward() is no_grad there too
+    assert not dw(x).requires_grad
+    eng = net.engine()
+    h = torch.zeros((1, 256, 512), device=dev)
+    pt = torch.zeros(256, device=dev)
+    ho, sk = torch.empty_like(h), torch.empty_like(h)
+    rc = eng.lib.ap_resblock_fwd(eng.ctx, 0, N.ptr(h), N.ptr(pt), N.ptr(ho), N.ptr(sk), 0, 1, 512, N.stream())
+    assert rc == -22 and b"AP_PREC_BF16_STORE" in eng.lib.ap_last_error()
+
+
+def test_bf16_store_chain_is_hip_graph_capturable(dh, dev):
+    """The mode's launches (37 per evaluation + the skip GEMM) capture into a HIP graph; a replay equals the eager call bit for bit."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    net, _ = _net(synth.mini_wavenet_config(256, 12, 12), dev, seed=4)
+    x = torch.from_numpy(synth.waveforms(3, 2000, seed=5)).to(dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+    eager = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+    eager.graph_replay = False
+    dw.set_noise_source(("philox", 21, 4))
+    eager.set_noise_source(("philox", 21, 4))
+    for xin in (x, x * 0.5, x):
+        assert torch.equal(dw(xin), eager(xin))
+    assert len(dw._graphs) == 1 and not eager._graphs
