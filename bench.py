@@ -31,10 +31,15 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# a ConvNet whose trace meets an operator without a kernel must fail the leg, not run on PyTorch operators behind a warning and
+# still report a throughput (audiopure_amd/convnet.py: NativeConvNet._off_native)
+os.environ.setdefault("AUDIOPURE_STRICT", "1")
 
 FLOP_PER_LAYER_UTT = 2.0 * 16000 * (512 * 768 + 512 * 256)      # 16.777 GFLOP: the layer as the reference states it
 FLOP_EXEC_F32W_UTT = 2.0 * 16000 * (512 * 512 + 512 * 256)      # 12.583 GFLOP: what the F(2,3) block executes (4 of 6 dilated-conv products)
 BYTES_PER_LAYER_UTT = (2 * 256 + 2 * 256) * 16000 * 4.0          # read h, write h', read+write skip (fp32)
+BYTES_PER_LAYER_UTT_BF16STORE = BYTES_PER_LAYER_UTT / 2.0        # SURVEY 8(d), bf16 storage: 1.180 GB per clip and step / 36 layers = 32.8 MB
+PEAK_BF16_MFMA_TFLOPS = 2500.0                                   # dense bf16 MFMA peak, MI355X_MICROARCH.md chip table
 PEAK_F32_MFMA_TFLOPS = 157.3                                     # MI355X_MICROARCH.md chip table
 N_LAYERS = 36
 
@@ -162,12 +167,13 @@ def cpu_baseline(budget_s: float = 25.0):
 
 PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32; dilated conv in F(2,3) minimal-filtering form)",
              "f32d": "fp32 (v_mfma_f32_32x32x2_f32; direct-form dilated conv: the round 1-4 kernel)", "bf16": "bf16",
+             "bf16s": "bf16 MFMA operands, fp32 accumulate, bf16 storage of the residual stream (SURVEY 8d's third precision row; fp32 skip)",
              "f32s": "fp32-class: exact 3-way bf16 operand split, 6 partial products on the bf16 MFMA, fp32 accumulate (direct-form "
                      "dilated conv; held to the fp32 tolerances and to 2 x the fp32 kernel's error on adversarial operands)"}
 
 
 PMC_FILES = {"f32": ["r5_f32w_pmc_traffic.json"], "f32d": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3_f32s_pmc_traffic.json", "r2_f32s_pmc_traffic.json"],
-             "bf16": ["r4_bf16_pmc_traffic.json"]}
+             "bf16": ["r6_bf16_pmc_traffic.json", "r4_bf16_pmc_traffic.json"], "bf16s": ["r6_bf16s_pmc_traffic.json"]}
 
 
 class PowerSampler:
@@ -454,8 +460,9 @@ def main():
     ap.add_argument("--reverse-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-modes", action="store_true", help="time only --precision (skip the bf16 / f32s / f32d legs)")
-    ap.add_argument("--precision", choices=["f32", "f32s", "bf16"], default="f32",
-                    help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage")
+    ap.add_argument("--precision", choices=["f32", "f32s", "bf16", "bf16s"], default="f32",
+                    help="f32 = exact fp32 MFMA (headline, BASELINE configs[1]); bf16 = bf16 MFMA operands, fp32 accumulate/storage; "
+                         "bf16s = the same with the residual stream stored as bf16")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
     ap.add_argument("--experimental-modes", action="store_true",
@@ -615,6 +622,30 @@ def main():
                     "note": "algorithmic fp32 flops; each is 6 v_mfma_f32_32x32x16_bf16 partial products (exact 3-way "
                             "bf16 operand split, fp32 accumulate), so peak = 2500 TFLOP/s dense bf16 / 6",
                     "executed_bf16_TFLOPs": round(6 * achieved, 1)}
+        elif precision == "bf16s":
+            # SURVEY 8(d), third precision row: bf16 MFMA + bf16 storage is COMPUTE-bound (830 against 1 356 utt/s per GPU), so the
+            # line is priced on the dense bf16 MFMA peak; the HBM side is reported beside it on bf16-storage algorithmic bytes
+            # (32.8 MB per clip and layer: read u, write u', read + write skip at two bytes per element).
+            sp = getattr(run_mode, "split", {})
+            gbs = BYTES_PER_LAYER_UTT_BF16STORE * B / (k_ms * 1e-3) / 1e9
+            roof = {"bound": "mfma",
+                    "kernel": "resblock_bf16u_kernel (persistent; bf16 u image in, u' + bf16 gate image out) + skipgemm_bf16_kernel (one "
+                              f"K-concatenated skip GEMM per {sp.get('skip_group', 0) or 36} layers)",
+                    "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "hbm": {"algorithmic_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 4),
+                            "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT_BF16STORE * B,
+                            "physical_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic else None,
+                            "note": "bf16-storage algorithmic bytes (SURVEY 8d: 32.8 MB per clip and layer); the kernels move u in, u' + a bf16 "
+                                    "gate image out, the image in once more and fp32 skip out once per group"},
+                    "per_layer_ms": {"block_launch": round(sp.get("block_ms", k_ms), 4),
+                                     "skip_gemm_share": round(sp.get("skip_gemm_ms_per_block_launch", 0.0), 4),
+                                     "skip_gemm_launches": sp.get("skip_gemm_launches", 0),
+                                     "skip_gemm_ms_per_launch": round(sp.get("skip_gemm_ms_per_launch", 0.0), 4)},
+                    "accounting": "achieved = the layer's algorithmic flops (16.777 GFLOP per clip: SURVEY 8d) / (block launch + its share of "
+                                  "the group's skip GEMM), against the dense bf16 MFMA peak",
+                    "note": "power-capped like AP_PREC_BF16 (see this leg's `power`): ~0.63 pJ per bf16 flop on random operands is 5.4 J "
+                            "per 512-clip launch = 3.9 ms at 1400 W before any byte moves (profiles/r3_mfma_power_calibration.txt)"}
         else:
             gbs = BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9
             sp = getattr(run_mode, "split", {})
@@ -639,10 +670,11 @@ def main():
                             "HBM-copy kernels (profiles/r3_mfma_power_calibration.txt: ~0.63 pJ per bf16 flop on random operands, ~120 pJ "
                             "per HBM byte) the ceiling of this algorithm under the cap is 0.48-0.54 of the 8 TB/s roofline; a synthetic kernel with the same "
                             "MFMA : HBM mix and nothing else measures 0.46-0.48 (profiles/r3_mfma_hbm_mix.txt, DESIGN.md 3.4)"}
+        bpl = BYTES_PER_LAYER_UTT_BF16STORE if precision == "bf16s" else BYTES_PER_LAYER_UTT
         roof.update({"traffic_source": traffic_source, "launches": launches, "clips_per_launch": B, "avg_launch_ms": round(k_ms, 4),
-                     "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": BYTES_PER_LAYER_UTT * B,
-                     "hbm_algorithmic_GBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 1e9, 1),
-                     "hbm_frac_of_8TBps": round(BYTES_PER_LAYER_UTT * B / (k_ms * 1e-3) / 8e12, 4)})
+                     "flop_per_launch": FLOP_PER_LAYER_UTT * B, "algorithmic_bytes_per_launch": bpl * B,
+                     "hbm_algorithmic_GBps": round(bpl * B / (k_ms * 1e-3) / 1e9, 1),
+                     "hbm_frac_of_8TBps": round(bpl * B / (k_ms * 1e-3) / 8e12, 4)})
         return roof
 
     elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
@@ -656,7 +688,7 @@ def main():
     # not the headline): same inputs, same chain, same timing brackets
     others = {}
     if world == 1 and not args.no_other_modes:
-        for prec in ("bf16", "f32s", "f32d", "f32"):
+        for prec in ("bf16", "bf16s", "f32s", "f32d", "f32"):
             if prec == args.precision:
                 continue
             if prec == "f32d" or (prec == "f32" and args.precision != "f32"):   # (one step: the direct-form A/B of the same run)
@@ -759,7 +791,7 @@ def main():
             "metric": f"purified 1s@16kHz utterances/sec at {n} reverse steps",
             "value": round(value, 3), "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32s" else args.precision, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.precision == "f32s" else ("bf16" if args.precision == "bf16s" else args.precision), "data": "synthetic",
             "config": {"workload": f"DiffWave {args.sampler.upper()} purify n={n} + M5 classify, batch={B}/GPU, 1 s @ 16 kHz "
                                    f"clips, {PREC_NAME[args.precision]} (BASELINE.json configs[{3 if args.precision == 'bf16' else 1}]); "
                                    "shipped config C=S=256, 36 layers",

@@ -2,6 +2,7 @@
 `rocprofv3 --kernel-trace --stats -- python3 tools/run_cfg4_step.py [B] [steps]`: the per-kernel split of the whole step
 (conv-as-GEMM family, GroupNorm, attention, mel, sampler updates)."""
 import os
+os.environ.setdefault("AUDIOPURE_STRICT", "1")
 import sys
 import time
 
