@@ -225,3 +225,26 @@ def test_winograd_form_holds_the_reference_golden_at_the_fp32_tolerances(golden,
     with torch.no_grad():
         epsm = O.eps_net(wm, cfgm, xm, 3.0 * torch.ones(2, 1), winograd=True)
     assert rel_err(epsm.numpy(), golden["mini/L4133/eps"]) < TOL_NET * 2
+
+
+def test_oracle_one_shot_votes_match_the_reference_smooth_predict(dh):
+    """The oracle's one-shot denoise + M5 on the certification loop's noisy copies (certified_robust.py:45-55: x + sigma z, scaled by
+    sqrt(alpha_bar*), one_shot_denoise at t*, classifier) against the scores the REFERENCE's RobustCertificate.smooth_predict
+    produced on the same Philox draws (tests/golden/make_golden_f2.py) -- pins the oracle, oracle/philox.py's keying and the
+    t* rule together.  First 8 of the 300 samples (CPU suite budget)."""
+    import os
+    from oracle.philox import philox_normal
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_f2_v1.npz"))
+    cfg = synth.mini_wavenet_config(64, 12, 12)
+    w = O.fold_state_dict(synth.wavenet_state_dict(cfg, 1))
+    sigma, n = 0.25, 8
+    ab_star = 1 / (1 + sigma ** 2)
+    t_star = int(torch.abs(dh["Alpha_bar"] - ab_star).min(0, keepdim=True)[1].item()) + 1      # certified_robust.py:99-107
+    assert t_star == int(g["cert/t_star"][0])
+    x = torch.from_numpy(synth.waveforms(1, 16000, seed=5))[0:1]
+    z = torch.from_numpy(philox_normal(77, 0, 0, n, 16000)).reshape(n, 1, 16000)
+    x_in = ab_star ** 0.5 * (x.repeat(n, 1, 1) + sigma * z)
+    lp = O.m5_forward(synth.m5_state_dict(10, seed=11), O.one_shot_denoise(w, cfg, dh, x_in, t_star)).numpy()
+    assert np.abs(lp - g["cert/scores"][:n]).max() < 1e-4
+    assert (lp.argmax(1) == g["cert/pred"][:n]).all()
+    assert int(g["cert/counts"].sum()) == 300 and (np.bincount(g["cert/pred"], minlength=10) == g["cert/counts"]).all()
