@@ -574,7 +574,7 @@ typedef unsigned int cu32x4 __attribute__((ext_vector_type(4)));
 
 typedef _Float16 ch16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ch16x2 __attribute__((ext_vector_type(2)));
-// AP_CONV_SPLIT_F16 (flags bit 10): the arithmetic of ap_resblock_f32h.hip -- operands as two fp16 parts (22 significant
+// AP_CONV_SPLIT_F16 (flags bit 10; not fp32-class: the residual-block mode with this arithmetic was removed in round 5) -- operands as two fp16 parts (22 significant
 // bits), three partial products on v_mfma_f32_32x32x16_f16, weights x 2^4 at pack time and activations x 2^4 at staging
 // (exact; the epilogue multiplies by 2^-8), scaled values clamped to +-60000.
 constexpr float CWSC = 16.0f, CXSC = 16.0f;

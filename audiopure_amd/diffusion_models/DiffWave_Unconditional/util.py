@@ -8,17 +8,24 @@ import torch
 
 
 def calc_diffusion_hyperparams(T, beta_0, beta_T):
-    """Same sequential fp32 products as the reference (util.py:111-118) -> dict of CPU tensors
-    with keys T, Beta, Alpha, Alpha_bar, Sigma (util.py:120-122)."""
-    Beta = torch.linspace(beta_0, beta_T, T)
-    Alpha = 1 - Beta
-    Alpha_bar = Alpha + 0
-    Beta_tilde = Beta + 0
-    for t in range(1, T):
-        Alpha_bar[t] *= Alpha_bar[t - 1]
-        Beta_tilde[t] *= (1 - Alpha_bar[t - 1]) / (1 - Alpha_bar[t])
-    Sigma = torch.sqrt(Beta_tilde)
-    return {"T": T, "Beta": Beta, "Alpha": Alpha, "Alpha_bar": Alpha_bar, "Sigma": Sigma}
+    """The DDPM schedule tables (reference: util.py:96-123) -> dict of CPU tensors with keys T, Beta, Alpha, Alpha_bar, Sigma.
+    alpha_bar is a running product taken one fp32 multiplication at a time (NOT cumprod: the two differ in the last bit from
+    t ~ 20 on, and the chain's coefficients are read from these tables), beta~_t = beta_t (1 - abar_{t-1}) / (1 - abar_t) with the
+    quotient formed first, beta~_0 = beta_0.  IEEE fp32 scalars throughout: bit-equal to the reference's tables
+    (tests/test_host_logic_cpu.py against tests/golden sched/*)."""
+    one = np.float32(1.0)
+    beta = torch.linspace(beta_0, beta_T, T)
+    b = beta.numpy()
+    alpha = (one - b).astype(np.float32)
+    alpha_bar, beta_tilde = np.empty(T, np.float32), np.empty(T, np.float32)
+    running = one
+    for t in range(T):
+        before = running
+        running = alpha[t] if t == 0 else np.float32(alpha[t] * before)
+        alpha_bar[t] = running
+        beta_tilde[t] = b[t] if t == 0 else np.float32(b[t] * np.float32(np.float32(one - before) / np.float32(one - running)))
+    return {"T": T, "Beta": beta, "Alpha": torch.from_numpy(alpha), "Alpha_bar": torch.from_numpy(alpha_bar),
+            "Sigma": torch.sqrt(torch.from_numpy(beta_tilde))}
 
 
 def embedding_frequencies(diffusion_step_embed_dim_in):

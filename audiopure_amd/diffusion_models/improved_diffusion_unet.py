@@ -151,9 +151,9 @@ class UNetModel(nn.Module):
 
     def set_precision(self, mode: str):
         """"f32": fp32 MFMA convolutions (default); "f32s": the bf16 MFMA with exactly 3-way-split fp32 operands
-        (AP_CONV_SPLIT): fp32-class results, faster; "f32h": two fp16 parts per operand on the fp16 MFMA
-        (AP_CONV_SPLIT_F16), faster again."""
-        self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100, "f32h": 0x400}[mode]
+        (AP_CONV_SPLIT): fp32-class results, faster; "f16x2" (round-3/4 name: "f32h"): two fp16 parts per operand on the fp16
+        MFMA (AP_CONV_SPLIT_F16), faster again and NOT fp32-class -- fine for this net's GroupNorm-ed activations only."""
+        self._conv_flags = {"f32": 0, "fp32": 0, "f32s": 0x100, "f32_split": 0x100, "f16x2": 0x400, "f32h": 0x400}[mode]
         return self
 
     def _conv(self, m, x, B, Cin, H, W, res=None, track=True, dest=None):

@@ -313,6 +313,33 @@ def device_descriptor(torch, local):
     return d
 
 
+def global_batch_shard(torch, world, rank, B, L, device, seed=1234):
+    """The GLOBAL batch of world * B synthetic clips (0.5 U(-1, 1)) from ONE seed, and this rank's contiguous shard of it: clip i of the
+    job is the same waveform however many ranks share the work (with the Philox noise keyed on the global index too, an N-rank run
+    reproduces the 1-rank run's scores bit for bit)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return (torch.rand((world * B, 1, L), device=device, generator=g) - 0.5)[rank * B:(rank + 1) * B].contiguous()
+
+
+def make_step(score_fn, x0, use_dist, n_total):
+    """One pass of the hot path over this rank's shard: `score_fn(x0)` -> [B, K] scores, then the path's only collective (an
+    all_gather of the score rows into global utterance order).  The timed loop of every leg and the CPU rehearsal call this."""
+    from audiopure_amd.sharding import all_gather_scores
+
+    def step():
+        lp = score_fn(x0)
+        return all_gather_scores(lp, n_total) if use_dist else lp
+    return step
+
+
+def scores_digest(scores):
+    """sha256 of the gathered [global_batch, K] scores: equal for every split of the same global batch over ranks."""
+    import hashlib
+    s = scores.detach().float().cpu().contiguous()
+    return {"shape": list(s.shape), "sha256": hashlib.sha256(s.numpy().tobytes()).hexdigest(), "argmax_head": s[:8].argmax(1).tolist()}
+
+
 def dry_run(args) -> None:
     """CPU rehearsal of the multi-rank protocol (gloo): shard bounds, barrier, the scores all_gather, max-over-ranks
     timing, one JSON line from rank 0.  No kernel runs and `value` is not a throughput."""
@@ -326,10 +353,12 @@ def dry_run(args) -> None:
     B = args.batch
     lo, hi = shard_bounds(world * B, rank, world)
     assert (lo, hi) == (rank * B, (rank + 1) * B)
-
-    def step():
-        lp = torch.full((B, 10), float(rank))
-        return all_gather_scores(lp, world * B) if use_dist else lp
+    # the real step function (global batch from one seed, contiguous shard, scores all_gather) around a CPU stand-in scorer whose
+    # row i depends on clip i only -- like the HIP path's -- so the gathered scores' digest must not depend on the split
+    Ld = 64
+    x0 = global_batch_shard(torch, world, rank, B, Ld, torch.device("cpu"))
+    wgt = torch.sin(torch.arange(10 * Ld, dtype=torch.float64).reshape(10, Ld) * 0.37).float()
+    step = make_step(lambda x: torch.log_softmax(8.0 * x.reshape(x.shape[0], -1) @ wgt.t(), dim=1), x0, use_dist, world * B)
 
     for _ in range(args.warmup):
         step()
@@ -346,13 +375,13 @@ def dry_run(args) -> None:
         t = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    assert lp.shape == (world * B, 10) and all(float(lp[r * B, 0]) == r for r in range(world))
+    assert lp.shape == (world * B, 10)
     if rank == 0:
         print(json.dumps({"metric": f"purified 1s@16kHz utterances/sec at {args.reverse_steps} reverse steps", "dry_run": True,
                           "value": None, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(el * 1e3 / max(args.steps, 1), 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": args.precision, "data": "none (protocol rehearsal on CPU, gloo)",
-                          "ranks": ranks,
+                          "ranks": ranks, "scores": scores_digest(lp),
                           "config": {"workload": "dry run: launcher + sharding + scores all_gather only",
                                      "global_batch": world * B, "parallelism": f"utterance-sharded x{world}, logits all_gather"}}),
               flush=True)
@@ -465,8 +494,6 @@ def main():
                          "bf16s = the same with the residual stream stored as bf16")
     ap.add_argument("--sampler", choices=["ddpm", "sde"], default="ddpm")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the BASELINE configs[3] / configs[4] legs")
-    ap.add_argument("--experimental-modes", action="store_true",
-                    help="(kept for old command lines; f32s is timed by default since round 5)")
     ap.add_argument("--no-caller-shapes", action="store_true", help="skip the callers' batch shapes leg (B = 1, 2, 10, 50, ...)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo rehearsal of the launch + gather protocol; no kernels")
     ap.add_argument("--chunk", type=int, default=0,
@@ -517,11 +544,7 @@ def main():
     m5.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.m5_state_dict(10).items()})
     m5 = m5.to(dev).eval()
     # synthetic 0.5*U(-1,1) clips, generated on device (resident in HBM before timing)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234)
-    # the GLOBAL batch from one seed, this rank's contiguous shard of it: clip i of the job is the same waveform however many ranks
-    # share the work (with the Philox noise keyed on the global index too, an N-rank run reproduces the 1-rank run's scores bit for bit)
-    x0_full = (torch.rand((world * B, 1, L), device=dev, generator=g) - 0.5)[rank * B:(rank + 1) * B].contiguous()
+    x0_full = global_batch_shard(torch, world, rank, B, L, dev)
 
     def fence():
         if use_dist:
@@ -548,11 +571,8 @@ def main():
         eng.max_chunk = args.chunk if args.chunk > 0 else B
         run_mode.chunk = min(eng.max_chunk, B)
 
-        def step():
-            lp = system(x0, True)                               # purify (n reverse steps) + classify, all in HIP
-            if use_dist:
-                return all_gather_scores(lp, world * B)         # the path's only collective: [B,10] scores / rank
-            return lp
+        # purify (n reverse steps) + classify, all in HIP; then the path's only collective: [B,10] scores / rank
+        step = make_step(lambda x: system(x, True), x0, use_dist, world * B)
 
         with torch.no_grad():
             for _ in range(warmup):
@@ -678,9 +698,7 @@ def main():
         return roof
 
     elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
-    import hashlib
-    head_scores = run_mode.last_scores.detach().float().cpu().contiguous()
-    scores_sha = hashlib.sha256(head_scores.numpy().tobytes()).hexdigest()
+    head_digest = scores_digest(run_mode.last_scores)
     head_power = run_mode.power
     head_roof = roofline(args.precision, k_ms, launches)        # (now: run_mode.chunk / .split describe the run just made)
     ranks = rank_evidence(use_dist, run_mode.local_elapsed, device_descriptor(torch, local), "nccl")
@@ -801,7 +819,7 @@ def main():
             "power": head_power,
             "ranks": ranks,
             # digest of the job's gathered [global_batch, 10] scores: equal for every split of the same global batch over ranks
-            "scores": {"shape": list(head_scores.shape), "sha256": scores_sha, "argmax_head": head_scores[:8].argmax(1).tolist()},
+            "scores": head_digest,
         }
         if others:
             out["other_modes"] = others

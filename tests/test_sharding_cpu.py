@@ -123,3 +123,27 @@ def test_bench_power_sampler_is_optional_evidence():
         time.sleep(0.1)
     r = ps.result()
     assert r is None or {"board_W_mean", "board_W_max", "cap_W", "sclk_MHz_mean", "samples"} <= set(r)
+
+
+def test_config2_split_reproduces_the_single_process_digest():
+    """BASELINE configs[2]'s split (4 096 clips as 8 x 512) through bench.py's REAL step function -- global batch from one seed,
+    contiguous shards, the scores all_gather, the `scores.sha256` digest of the line -- around a CPU stand-in scorer (gloo): the
+    8-rank digest must equal the 1-rank digest of the same global batch.  The two-rank RCCL test on hardware
+    (tests/test_gpu_dropin.py) relies on exactly this plumbing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    digests = {}
+    for gpus, batch in ((1, 4096), (8, 512), (2, 2048)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--dry-run", "--steps", "1", "--warmup", "0",
+                            "--batch", str(batch)], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["config"]["global_batch"] == 4096 and out["scores"]["shape"] == [4096, 10]
+        digests[gpus] = out["scores"]["sha256"]
+    assert digests[8] == digests[1] == digests[2], digests

@@ -38,7 +38,7 @@ def main():
     w = O.fold_state_dict(sd)
     w64 = {k: v.double() for k, v in w.items()}
     B, C, L = 2, 256, 2048
-    modes = sys.argv[1:] or ["f32d", "f32", "f32s", "f32h"]
+    modes = sys.argv[1:] or ["f32d", "f32", "f32s"]
     res = {}
     for layer in (2, 7):
         d = 2 ** layer

@@ -6,7 +6,7 @@ repo=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$(dirname "$repo/$out")"
 {
 echo "== idle"; rocm-smi --showpower --showclocks --showmaxpower 2>&1 | grep -E "Power|sclk|mclk|Max" | head -8
-for spec in "512 bf16 150 9" "512 f32s 40 9" "512 f32h 70 9" "256 f32 40 9"; do
+for spec in "512 bf16 150 9" "512 f32s 40 9" "256 f32 40 9"; do
   echo "== run_resblock_layers $spec"
   python3 "$repo/tools/run_resblock_layers.py" $spec > /dev/null 2>&1 &
   pid=$!

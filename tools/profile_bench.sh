@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile set for one precision: bench line, rocprofv3 kernel stats, HBM traffic PMC passes.
-# usage: tools/profile_bench.sh <f32|f32s|f32h|bf16> <outdir under gpurun_out>
+# usage: tools/profile_bench.sh <f32|f32s|bf16|bf16s> <outdir under gpurun_out>
 prec=${1:-f32}; out=${2:-gpurun_out/prof_$prec}
 repo=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$repo/$out"; cd /tmp; export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 """Phase timeline of the split-precision residual-block kernels (s_memtime stamps of all 8 waves, ap_debug_trace):
-python tools/trace_resblock_f32s.py [B] [layer] [f32s|f32h]"""
+python tools/trace_resblock_f32s.py [B] [layer]"""
 import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702  (-DAP_TOOLS library)
 import sys, os, ctypes as C, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 lib.ap_debug_trace(None)
 t = tr.cpu().numpy().reshape(nblk, 8, 16).astype(np.int64)
 sel = slice(nblk // 4, 3 * nblk // 4) if nblk > 1024 else slice(0, nblk)
-H = len(sys.argv) > 3 and sys.argv[3] == "f32h"
+H = False                                                    # (the fp16-split block of rounds 3-4 is gone)
 seq = [0, 1, 2, 3, 4, 5, 6, 14] if H else [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14]
 names = ["prologue", "iter0 (2 chunks)", "iters1-3", "iters4-7", "gate + barrier", "g2 pass0", "g2 pass1"] if H else ["prologue", "iter0 (2 chunks)", "iters1-3", "iters4-7", "gate h0", "g2 h0 pass0", "g2 h0 pass1", "gate h1", "g2 h1 pass0", "g2 h1 pass1"]
 for w in (0, 4, 7):
@@ -34,12 +34,6 @@ for w in (0, 4, 7):
     print(f"wave {w}: total median {np.median(tt[:, -1] - tt[:, 0]):.0f} cycles")
     for i, n in enumerate(names):
         print(f"   {n:18s} median {np.median(d[:, i]):8.0f}")
-    if len(sys.argv) > 3 and sys.argv[3] == "f32h":
-        c = t[sel, w][:, [5, 10, 11, 12, 13]]
-        c1 = t[sel, w][:, [15, 7, 8, 9]]
-        print("   iteration 4, first chunk: kstep0 %.0f  ksteps1-2 + pack %.0f  barrier %.0f" % tuple(np.median(np.diff(c1, axis=1), axis=0)))
-        print("   g2 pass0: setup %.0f  first 2 k-steps %.0f  rest of GEMM %.0f  epilogue %.0f" % tuple(np.median(np.diff(c, axis=1), axis=0)))
-        continue
     c = t[sel, w][:, [3, 10, 11, 12, 13]]
     dd = np.median(np.diff(c, axis=1), axis=0)
     print("   iteration 4, first chunk: kstep0 %.0f  ksteps1-2 %.0f  pack+store %.0f  barrier %.0f" % tuple(dd))
