@@ -107,8 +107,8 @@ extern "C" int ap_ctx_create(const ap_config *cfg, ap_ctx **out) {
   c->slab_bb = nullptr;
   c->w2t = c->w1b = nullptr;
   c->bwd_ready = false;
-  c->f32_form = 1;
-  c->w1p_s = c->w2p_s = nullptr;
+  c->f32_form = cfg->precision == AP_PREC_F32_SPLIT ? 0 : 1;     // (the split mode's F(2,3) form is opt-in: measured +3 %, looser adversarial bound)
+  c->w1p_s = c->w2p_s = c->w1w_s = nullptr;
   c->profile = false;
   c->ev_used = 0;
   c->skip_group = 0;
@@ -204,13 +204,19 @@ extern "C" int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group) {
 extern "C" int ap_ctx_set_f32_form(ap_ctx *ctx, int form) {
   if (!ctx) { set_error("ap_ctx_set_f32_form: null ctx"); return -22; }
   if (form != 0 && form != 1) { set_error("ap_ctx_set_f32_form: form %d (0 direct, 1 minimal-filtering)", form); return -22; }
-  if (ctx->cfg.precision != AP_PREC_F32) { set_error("ap_ctx_set_f32_form: AP_PREC_F32 contexts only"); return -22; }
+  if (ctx->cfg.precision != AP_PREC_F32 && ctx->cfg.precision != AP_PREC_F32_SPLIT) {
+    set_error("ap_ctx_set_f32_form: AP_PREC_F32 / AP_PREC_F32_SPLIT contexts only");
+    return -22;
+  }
   ctx->f32_form = form;
   return 0;
 }
 
 extern "C" int ap_ctx_get_f32_form(ap_ctx *ctx) {
-  return ctx && ctx->cfg.precision == AP_PREC_F32 && ctx->f32_form == 1 && ctx->C == 256 && ctx->S == 256 ? 1 : 0;
+  return ctx && (ctx->cfg.precision == AP_PREC_F32 || ctx->cfg.precision == AP_PREC_F32_SPLIT) && ctx->f32_form == 1 && ctx->C == 256 &&
+                 ctx->S == 256
+             ? 1
+             : 0;
 }
 
 extern "C" int ap_ctx_set_schedule(ap_ctx *ctx, const float *beta, const float *alpha, const float *alpha_bar,
@@ -313,13 +319,19 @@ extern "C" int ap_ctx_load_wavenet(ap_ctx *ctx, const float *blob_dev, size_t n_
   }
   if (c.precision == AP_PREC_F32_SPLIT) {
     const size_t n1 = NL * 2 * C * C * 3, n2 = NL * (C + S) * C;
+    const size_t n1w = (C == 256 && S == 256) ? NL * 4 * 2 * C * C : 0;    // F(2,3)-transformed GEMM1 image (ap_resblock_f32s2.hip)
     if (!ctx->slab_s) {
-      AP_HIP(hipMalloc(&ctx->slab_s, (n1 + n2) * 3 * 2));
+      AP_HIP(hipMalloc(&ctx->slab_s, (n1 + n2 + n1w) * 3 * 2));
       ctx->w1p_s = ctx->slab_s;
       ctx->w2p_s = (char *)ctx->slab_s + n1 * 3 * 2;
+      ctx->w1w_s = n1w ? (char *)ctx->slab_s + (n1 + n2) * 3 * 2 : nullptr;
     }
     rc = launch_pack_split(ctx, st);
     if (rc) return rc;
+    if (ctx->w1w_s) {
+      rc = launch_pack_split23(ctx, st);
+      if (rc) return rc;
+    }
   }
   AP_HIP(hipStreamSynchronize(st));
   ctx->loaded = true;

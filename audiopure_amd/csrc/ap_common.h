@@ -95,6 +95,7 @@ struct ap_ctx {
   void *w1q_bf;             // GEMM1 image for v_mfma_f32_16x16x32_bf16 (same allocation, behind wf1p_bf)
   void *slab_bf;
   void *w1p_s, *w2p_s;      // 3-way bf16-split images (AP_PREC_F32_SPLIT), own allocation
+  void *w1w_s;              // ... and the F(2,3)-transformed, 3-way-split GEMM1 image of ap_resblock_f32s2.hip (same allocation)
   void *slab_s;
   float *w1w, *w2w;         // AP_PREC_F32, C = S = 256: F(2,3)-transformed GEMM1 image and GEMM2 image of ap_resblock_f32w.hip, own allocation
   void *slab_w;
@@ -102,7 +103,7 @@ struct ap_ctx {
   void *slab_b;
   void *slab_bb;            // bf16 backward images of ap_resblock_bwd_bf16.hip (ap_ctx_prepare_backward)
   bool bwd_ready;           // the backward images of this context's precision are built from the weights now loaded
-  int f32_form;             // AP_PREC_F32: 1 = minimal-filtering (Winograd) block where built (default), 0 = direct-form block
+  int f32_form;             // AP_PREC_F32 / AP_PREC_F32_SPLIT: 1 = minimal-filtering (F(2,3)) block where built (default), 0 = direct-form block
   float *norms;           // scratch for row norms
   // optional per-launch timing of the residual-block kernel (bench.py roofline leg)
   bool profile;
@@ -211,6 +212,10 @@ bool resblock_f32w_serves(const ap_ctx *ctx, int B, int L);       // AP_PREC_F32
 int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                          int accumulate, int B, int L, hipStream_t st, float *aout = nullptr);   // hout null: the net's last layer (no res_conv, no h'); returns 1 if the shape is not served
 int launch_pack_split(ap_ctx *ctx, hipStream_t st);
+int launch_pack_split23(ap_ctx *ctx, hipStream_t st);            // ap_resblock_f32s2.hip: AP_PREC_F32_SPLIT with the dilated conv in F(2,3) form
+bool resblock_split23_serves(const ap_ctx *ctx, int B, int L);
+int launch_resblock_split23(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate, int B, int L,
+                            hipStream_t st);
 int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
                           int accumulate, int B, int L, hipStream_t st);
 int prepare_bwd_f32(ap_ctx *ctx, hipStream_t st);                // ap_ctx_prepare_backward, per precision (allocate + pack + synchronise)

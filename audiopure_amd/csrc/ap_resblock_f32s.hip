@@ -514,6 +514,8 @@ int launch_resblock_split(ap_ctx *ctx, int layer, const float *hin, const float 
     set_error("AP_PREC_F32_SPLIT is built for res_channels = skip_channels = 256 only (got %d, %d)", C, S);
     return -22;
   }
+  // the dilated conv in F(2,3) form where built and selected (ap_resblock_f32s2.hip: 3/4 of this kernel's matrix work)
+  if (hout && resblock_split23_serves(ctx, B, L)) return launch_resblock_split23(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const int ntiles = (L + BT - 1) / BT;
   const int nblk = B * ntiles;

@@ -204,12 +204,14 @@ class WaveNet_Speech_Commands(nn.Module):
         residual stream stored as bf16 between layers (SURVEY.md 8d "bf16 MFMA, bf16 storage"; one more rounding per layer,
         forward only).  All but "f32" need res_channels = 256."""
         modes = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "f32d": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
-                 "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "bf16s": N.AP_PREC_BF16_STORE,
+                 "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "f32sw": N.AP_PREC_F32_SPLIT, "bf16s": N.AP_PREC_BF16_STORE,
                  "bf16_store": N.AP_PREC_BF16_STORE}
         if mode not in modes:
             raise ValueError(f"set_precision: unknown mode {mode!r} (one of {sorted(modes)}; 'f32h' was removed in round 5)")
         prec = modes[mode]
-        self._f32_form = 0 if mode == "f32d" else 1
+        # "f32sw": the split mode with the dilated conv in F(2,3) form (two launches per block, ap_resblock_f32s2.hip): opt-in -- 3-4 %
+        # faster than "f32s" (both power-capped) and with the F(2,3) form's looser bound on a 2^40 dynamic range
+        self._f32_form = 0 if mode in ("f32d", "f32s", "f32_split") else 1
         if prec != self._precision:
             self._precision = prec
             self._engine = None
@@ -243,7 +245,7 @@ class WaveNet_Speech_Commands(nn.Module):
                 freq = embedding_frequencies(self.config["diffusion_step_embed_dim_in"]).to(dev).contiguous()
                 self._engine.load(blob, freq)
             self._engine.loaded_key = key
-        if self._precision == N.AP_PREC_F32:
+        if self._precision in (N.AP_PREC_F32, N.AP_PREC_F32_SPLIT):
             N.check(self._engine.lib.ap_ctx_set_f32_form(self._engine.ctx, int(self._f32_form)), "ap_ctx_set_f32_form")
         return self._engine
 

@@ -215,6 +215,12 @@ int ap_resblock_fwd_u(ap_ctx *ctx, int layer, const void *u_in, const float *par
  * [2C x C] products instead of six (block: 12.58 GFLOP per clip instead of 16.78) on the exact-fp32 matrix instruction;
  * transformed weights are computed in double at load, results differ from the direct form by fp32 rounding only and meet the
  * same tolerances against the reference's vectors.  0: the direct form (every other shape always runs it).
+ * AP_PREC_F32_SPLIT contexts take the same switch (round 6) but default to 0: form 1 runs the block as two launches -- GEMM1 in
+ * F(2,3) form over half of the gate channels per workgroup + the gate, g handed on as fp32 through h_out, then [res_conv; skip_conv] g
+ * with the block's epilogues in place (ap_resblock_f32s2.hip) -- 3/4 of the direct split kernel's matrix work at the same 5e-6
+ * block tolerance, but only 3-4 % faster (both forms sit at the board's power cap; the second launch's traffic and the doubled
+ * staging eat the saved matrix energy) and, like the fp32 F(2,3) form, up to 3 x the direct fp32 kernel's error on a 2^40 dynamic
+ * range (the direct split form stays within 2 x): opt-in, not the default.
  * ap_ctx_get_f32_form returns the form the block launches of this context will use. */
 int ap_ctx_set_f32_form(ap_ctx *ctx, int form);
 int ap_ctx_get_f32_form(ap_ctx *ctx);

@@ -124,6 +124,42 @@ def winograd_dilated_conv(u: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, 
     return y
 
 
+def winograd4_dilated_conv(u: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, d: int) -> torch.Tensor:
+    """The same conv in F(4,3) form over dilation QUADS (a CPU-only numerics gate: VERDICT r5 item 6b; no kernel computes this):
+    outputs t, t + d, t + 2d, t + 3d share the six taps u[t - d] .. u[t + 4d], so the quad costs six [2C x C] products instead of
+    twelve (the F(2,3) form: eight).  Lavin & Gray's transform matrices; transformed weights in double, rounded to fp32 once;
+    input and output transforms in fp32.  Samples t with floor(t / d) % 4 == 0 are a quad's first output."""
+    B, C, L = u.shape
+    W64 = W.double()
+    g0, g1, g2 = W64[:, :, 0], W64[:, :, 1], W64[:, :, 2]
+    G = [g0 / 4, -(g0 + g1 + g2) / 6, -(g0 - g1 + g2) / 6, g0 / 24 + g1 / 12 + g2 / 6, g0 / 24 - g1 / 12 + g2 / 6, g2]
+    G = [g.float() for g in G]
+    t = torch.arange(L)
+    tf = t[(t // d) % 4 == 0]
+
+    def tap(off):
+        idx = tf + off
+        ok = (idx >= 0) & (idx < L)
+        v = u[:, :, idx.clamp(0, L - 1)]
+        return torch.where(ok, v, torch.zeros((), dtype=u.dtype))
+
+    x0, x1, x2, x3, x4, x5 = (tap(k * d) for k in range(-1, 5))
+    D = [4 * x0 - 5 * x2 + x4, -4 * x1 - 4 * x2 + x3 + x4, 4 * x1 - 4 * x2 - x3 + x4, -2 * x1 - x2 + 2 * x3 + x4,
+         2 * x1 - x2 - 2 * x3 + x4, 4 * x1 - 5 * x3 + x5]
+    M = [torch.einsum("oc,bcp->bop", G[k], D[k]) for k in range(6)]
+    bb = bias.view(1, -1, 1)
+    ys = [(((M[0] + M[1]) + M[2]) + M[3]) + M[4] + bb,
+          ((M[1] - M[2]) + 2 * (M[3] - M[4])) + bb,
+          ((M[1] + M[2]) + 4 * (M[3] + M[4])) + bb,
+          (((M[1] - M[2]) + 8 * (M[3] - M[4])) + M[5]) + bb]
+    y = torch.empty(B, W.shape[0], L, dtype=u.dtype)
+    for k in range(4):
+        ts = tf + k * d
+        ok = ts < L
+        y[:, :, ts[ok]] = ys[k][:, :, ok]
+    return y
+
+
 def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.Tensor, bf16_operands: bool = False,
                    winograd: bool = False, bf16_store: bool = False):
     """One ``Residual_block.forward`` (WaveNet.py:75-97).
@@ -144,7 +180,9 @@ def residual_block(w: dict, n: int, dilation: int, x: torch.Tensor, emb: torch.T
     u = x + part_t                                                                       # :84 (alias!)
     if bf16_store:
         u = _bf16(u)
-    if winograd:
+    if winograd == 4:                                            # (True == 1: the F(2,3) form below)
+        h = winograd4_dilated_conv(u, w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"], dilation)
+    elif winograd:
         h = winograd_dilated_conv(u, w[p + ".dilated_conv_layer.conv.weight"], w[p + ".dilated_conv_layer.conv.bias"], dilation)
     else:
         h = F.conv1d(q(u), q(w[p + ".dilated_conv_layer.conv.weight"]), w[p + ".dilated_conv_layer.conv.bias"],
