@@ -596,6 +596,20 @@ extern "C" int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, c
   return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, nullptr, 0, B, L, (hipStream_t)stream, nullptr, nullptr, g_image);
 }
 
+extern "C" size_t ap_gate_factor_bytes(int B, int L) {
+  if (B < 1 || L < 1) return 0;
+  return (size_t)B * (size_t)((L + 127) / 128) * 131072u;
+}
+
+extern "C" int ap_resblock_fwd_gate_save(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out,
+                                         void *g_image, void *gate_factors, int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !h_in || !part_t_layer || !g_image || !gate_factors) { set_error("ap_resblock_fwd_gate_save: not loaded / null"); return -22; }
+  if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd_gate_save: layer=%d B=%d L=%d", layer, B, L); return -22; }
+  if (h_in == h_out) { set_error("ap_resblock_fwd_gate_save: h_out must not alias h_in"); return -22; }
+  if (ctx->cfg.precision != AP_PREC_BF16) { set_error("ap_resblock_fwd_gate_save: AP_PREC_BF16 only"); return -22; }
+  return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, nullptr, 0, B, L, (hipStream_t)stream, nullptr, nullptr, g_image, gate_factors);
+}
+
 extern "C" int ap_skip_gemm(ap_ctx *ctx, int layer0, int n_layers, const void *g_images, float *skip, int accumulate_skip,
                             int B, int L, void *stream) {
   if (!ctx || !ctx->loaded || !g_images || !skip) { set_error("ap_skip_gemm: not loaded / null"); return -22; }

@@ -181,7 +181,8 @@ struct UbArgs {
 };
 int launch_make_ub(const float *h, const float *pt, void *ub, int B, int C, int L, hipStream_t st);
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr, const UbArgs *ub = nullptr, void *gout = nullptr);
+                    int accumulate, int B, int L, hipStream_t st, float *aout = nullptr, const UbArgs *ub = nullptr, void *gout = nullptr,
+                    void *fout = nullptr);
 int launch_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out, float ca,
                         float cb, float cs, const float *z, uint64_t seed, uint32_t draw, uint64_t utt_offset,
                         int B, int L, hipStream_t st);
@@ -197,9 +198,10 @@ int launch_final_affine_bf16(ap_ctx *ctx, const float *skip, const float *x, flo
 bool resblock_bf16s_serves(const ap_ctx *ctx, int B, int L);
 int launch_resblock_bf16s(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, void *gout, int B, int L, hipStream_t st);
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);
+                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr, void *fout = nullptr);
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr);   // persistent form; returns 1 if the shape is not served
+                          int accumulate, int B, int L, hipStream_t st, const UbArgs *ub = nullptr, void *gout = nullptr, void *fout = nullptr);   // persistent form; returns 1 if the shape is not served
+                                                                  // (fout, with gout: + the gate's derivative factors, 128 KB per 128-sample tile)
 // AP_PREC_BF16_STORE (ap_resblock_bf16u.hip): the residual stream as bf16 images of u = h + part_t, [clip][C / 32][L][32]
 bool resblock_bf16u_serves(const ap_ctx *ctx, int L);
 int launch_init_conv_u(ap_ctx *ctx, const float *x, const float *pt0, void *u, int B, int L, hipStream_t st);

@@ -546,7 +546,7 @@ static int g_ablate = 0;       // timing-only ablation mask (ap_debug_ablate)
 #endif
 
 int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                    int accumulate, int B, int L, hipStream_t st, float *aout, const UbArgs *ub, void *gout) {
+                    int accumulate, int B, int L, hipStream_t st, float *aout, const UbArgs *ub, void *gout, void *fout) {
   if (aout && ctx->cfg.precision != AP_PREC_F32) {
     set_error("ap_resblock_fwd_save: fp32 arithmetic only (the other modes recompute the pre-gate activations)");
     return -22;
@@ -576,9 +576,9 @@ int launch_resblock(ap_ctx *ctx, int layer, const float *hin, const float *pt, f
       AP_HIP(hipEventRecord(e0, st));
     }
     int rc = ctx->cfg.precision == AP_PREC_BF16
-                 ? (gout && !ub && g_no_bf16s != 1 && (g_no_bf16s == 2 || resblock_bf16s_serves(ctx, B, L))
+                 ? (gout && !ub && !fout && g_no_bf16s != 1 && (g_no_bf16s == 2 || resblock_bf16s_serves(ctx, B, L))
                         ? launch_resblock_bf16s(ctx, layer, hin, pt, hout, gout, B, L, st)     // small batches: half-size tiles, bit-identical
-                        : launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout))
+                        : launch_resblock_bf16(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout, fout))
                  : launch_resblock_split(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st);
     if (e1) AP_HIP(hipEventRecord(e1, st));
     return rc;

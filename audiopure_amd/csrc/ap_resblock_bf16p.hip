@@ -63,6 +63,31 @@ __device__ __forceinline__ f32x2 gate_fast2(f32x2 a, f32x2 b) {
   return (1.0f - E) * r;
 }
 
+// gate_fast2 that also hands out the gate's two derivative factors (the white-box backward's operands: ap_resblock_bwd_bf16.hip):
+// f1 = d(tanh . sigmoid)/d(tanh arg) = sg (1 - th^2), f2 = d/d(sigmoid arg) = th sg (1 - sg), from the quantities the gate forms anyway
+// (sg = (1 + E) r, th = g (1 + F), th sg = g).  The returned gate is gate_fast2's, operation for operation: a forward pass that keeps
+// the factors writes the same h' and g image as one that does not.  F = +inf (sigmoid argument below -88): g = sg = 0 and 0 . inf is
+// taken as 0.
+__device__ __forceinline__ f32x2 gate_fast2_save(f32x2 a, f32x2 b, f32x2 &f1, f32x2 &f2) {
+#pragma clang fp contract(off)                                  // one operation order in every instantiation (1 - th th as an fma in some, not in others: seen)
+  const f32x2 ac = {__builtin_amdgcn_fmed3f(a[0], -16.0f, 16.0f), __builtin_amdgcn_fmed3f(a[1], -16.0f, 16.0f)};
+  const f32x2 ea = ac * -2.885390081777926815f;
+  const f32x2 eb = b * -1.442695040888963407f;
+  const f32x2 E = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+  const f32x2 F = {__builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+  const f32x2 opE = E + 1.0f, opF = F + 1.0f;
+  const f32x2 den = opE * opF;
+  const f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 g = (1.0f - E) * r;
+  const f32x2 sg = opE * r;
+  f32x2 th = g * opF;
+  th[0] = F[0] > 3.0e38f ? 0.f : th[0];
+  th[1] = F[1] > 3.0e38f ? 0.f : th[1];
+  f1 = sg * (1.0f - th * th);
+  f2 = g * (1.0f - sg);
+  return g;
+}
+
 using I0 = std::integral_constant<int, 0>;
 using I1 = std::integral_constant<int, 1>;
 using I2 = std::integral_constant<int, 2>;
@@ -234,15 +259,22 @@ __device__ unsigned long long *g_ptrace = nullptr;               // DBG 2048: [w
 // (same pass-0 code); per tile and layer the block moves 131 KB in + 131 KB + 64 KB out instead of 262 + 262 KB.
 // NOH (with DS): the net's LAST layer -- its h' is never read (WaveNet.py:131-135 returns only the skip sum), so res_conv, the
 // residual's re-read of h and the h' store are left out: GEMM1, the gate and the g image only.
-template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false, bool DS = false, bool NOH = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
+// SAVEF (with DS; the differentiable purifier's forward pass, ap_resblock_fwd_gate_save): the gate's two derivative factors are also
+// written, as an fp16 pair per (channel, sample), in the ORDER THE ACCUMULATORS HOLD THEM -- [clip][tile][wave 8][column tile 4][q 4][lane 64]
+// x 16 bytes (128 KB per tile): one 16-byte store per lane and (column tile, q), 1 KB contiguous per wave; the backward's gate kernel has
+// the same wave / lane / register geometry and reads them back the same way (ap_resblock_bwd_bf16.hip).  h' and the g image are
+// bit-identical to the launch without it.
+template <int DBG, int WS = -1, bool RAG = false, bool M16 = false, bool UB = false, bool DS = false, bool NOH = false, bool SAVEF = false>   // WS >= 0: window staging (d <= 32); WS = d mod 4 as far as the code needs it: 0, 1 (d = 1), 2 (d = 2)
 __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
     const void *__restrict__ bbase, unsigned bbytes, unsigned b1_off, unsigned b2_off,        // fp32 bias vectors (one slab)
     int L, int d, int accumulate, int ntiles, int nblk,
     const void *__restrict__ ubin, void *__restrict__ ubout, const float *__restrict__ ptn,     // UB: bf16 operand images in / out (out may be null), the next layer's part_t
-    void *__restrict__ gout) {                                                                  // DS: this layer's g image [clip][L][256] bf16
+    void *__restrict__ gout,                                                                    // DS: this layer's g image [clip][L][256] bf16
+    void *__restrict__ fout = nullptr) {                                                        // SAVEF: the gate's derivative factors
   constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
+  static_assert(!SAVEF || (DS && !M16), "SAVEF: a form of the deferred-skip block");
   static_assert(!UB || (WS < 0 && !M16), "UB: one staging form");
   static_assert(!DS || (!UB && !M16), "DS: the product staging forms only");
   static_assert(!NOH || DS, "NOH: a form of the deferred-skip block");
@@ -928,14 +960,33 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16p_kernel(
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
         unsigned pk[2];
+        u32x4 fq;
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const f32x2 a2 = {acc[0][ct][4 * qq + e], acc[0][ct][4 * qq + e + 1]};
           const f32x2 b2 = {acc[1][ct][4 * qq + e], acc[1][ct][4 * qq + e + 1]};
-          const f32x2 g2 = (DBG & 32) ? a2 + b2 : gate_fast2(a2, b2);
+          f32x2 g2;
+          if constexpr (SAVEF) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            f32x2 f1, f2;
+            g2 = gate_fast2_save(a2, b2, f1, f2);
+            fq[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{f1[0], f2[0]}, f16x2));       // (tanh factor, sigmoid factor) of element e
+            fq[e + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{f1[1], f2[1]}, f16x2));
+          } else {
+            g2 = (DBG & 32) ? a2 + b2 : gate_fast2(a2, b2);
+          }
           pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(g2, bf16x2));
         }
         *reinterpret_cast<uint2 *>(lds + GOFF + ((32 * ct + j) * GS_ + 32 * wave + 8 * qq + 4 * hh) * 2) = make_uint2(pk[0], pk[1]);
+        if constexpr (SAVEF) {
+          const uint64_t fb = (uint64_t)fout + (uint64_t)b_cur * ((uint64_t)ntiles * 131072u);
+          const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)fb), fhi = __builtin_amdgcn_readfirstlane((uint32_t)(fb >> 32));
+          const __amdgpu_buffer_rsrc_t frs =
+              __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)fhi << 32) | flo), 0, (int)((unsigned)ntiles * 131072u), 0x00020000);
+          // (the whole offset in the VGPR, soffset = 0: a >8-byte buffer store with an SGPR soffset reads its data late and the compiler
+          //  does not guard the next write of those VGPRs -- the torn lanes of round 1, seen again here in the window-staging instantiations)
+          __builtin_amdgcn_raw_buffer_store_b128(fq, frs, (unsigned)ln * 16u + (unsigned)((((t0 / PT_) * 8 + wave) * 16 + ct * 4 + qq) * 1024), 0, NTS);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -1162,7 +1213,7 @@ namespace ap {
 
 // -> 0 launched, 1 shape not served by this kernel (caller falls back to the per-tile kernel)
 int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                          int B, int L, hipStream_t st, const UbArgs *ub, void *gout) {
+                          int B, int L, hipStream_t st, const UbArgs *ub, void *gout, void *fout) {
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   if (C != 256 || S != 256 || L < 1) return 1;
@@ -1197,9 +1248,16 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
                                                                     b1_off, b2_off, L, d, accumulate, ntiles, nblk, nullptr, nullptr, nullptr, nullptr)
   if (gout) {                                                    // deferred-skip form: h' + the bf16 g image, no skip GEMM in the block
     if ((size_t)L * 512 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16: clip too long for the bf16 g image"); return -22; }
+    if (fout && (size_t)ntiles * 131072 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16: clip too long for the gate-factor image"); return -22; }
 #define AP_P_LAUNCH_DS(W, R)                                                                                                   \
   do {                                                                                                                         \
-    if (hout)                                                                                                                  \
+    if (fout && hout) /* the differentiable purifier's forward: + the gate's derivative factors */                             \
+      resblock_bf16p_kernel<0, W, R, false, false, true, false, true><<<(unsigned)grid, 512, 0, st>>>(                         \
+          hin, pt, hout, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr, nullptr, nullptr, gout, fout); \
+    else if (fout)                                                                                                             \
+      resblock_bf16p_kernel<0, W, R, false, false, true, true, true><<<(unsigned)grid, 512, 0, st>>>(                          \
+          hin, pt, nullptr, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr, nullptr, nullptr, gout, fout); \
+    else if (hout)                                                                                                             \
       resblock_bf16p_kernel<0, W, R, false, false, true><<<(unsigned)grid, 512, 0, st>>>(                                      \
           hin, pt, hout, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d, 0, ntiles, nblk, nullptr, nullptr, nullptr, gout); \
     else /* h' not wanted (the net's last layer) */                                                                            \
@@ -1318,12 +1376,12 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 // (C = S = 256; any dilation of a power-of-two cycle, any clip length).  The one-tile-per-workgroup kernel of round 1
 // (tools/csrc/ap_resblock_bf16.hip) is compiled into the tools library only, as the A/B baseline of tools/cmp_bf16_kernels.py.
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip, int accumulate,
-                         int B, int L, hipStream_t st, const UbArgs *ub, void *gout) {
+                         int B, int L, hipStream_t st, const UbArgs *ub, void *gout, void *fout) {
   if (ctx->C != 256 || ctx->S != 256) {
     set_error("AP_PREC_BF16 is built for res_channels = skip_channels = 256 only (got %d / %d)", ctx->C, ctx->S);
     return -22;
   }
-  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout);
+  const int rc = launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout, fout);
   if (rc == 1) {
     set_error("AP_PREC_BF16: shape not served (layer %d, L = %d)", layer, L);
     return -22;

@@ -319,6 +319,132 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_bf16_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// K1 from KEPT gate factors (round 6): the forward pass that runs for a gradient (ap_resblock_fwd_gate_save) writes the gate's two
+// derivative factors as an fp16 pair per (channel, sample) in its accumulators' order (ap_resblock_bf16p.hip, SAVEF: 128 KB per
+// 128-sample tile), so this launch neither recomputes the dilated conv (3/4 of K1's matrix work, its X staging) nor evaluates a
+// transcendental: dg = [sqrt(1/2) W_res; W_skip]^T [dh'; dskip], dy = factor . dg.  Same tile / wave / lane / register geometry as the
+// forward's gate phase: lane l of wave w reads back, per (column tile, q), the 16 bytes it wrote.
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const float *__restrict__ dh, const float *__restrict__ dskip,
+                                                                         const void *__restrict__ fac, __bf16 *__restrict__ dy,
+                                                                         const __bf16 *__restrict__ w2t, int L, int ntiles) {
+  constexpr int C = QC_;
+  constexpr int NT = 128;
+  constexpr int ZB = NT * ZSB2_;
+  __shared__ __attribute__((aligned(16))) __bf16 lds[NT * DSB_];   // 133 KB: the dy tile of the epilogue; the Z ring aliases its start
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  const unsigned tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int b = __builtin_amdgcn_readfirstlane((int)(tile / ntiles));
+  const int ti = __builtin_amdgcn_readfirstlane((int)(tile % ntiles));
+  const int t0 = ti * NT;
+  auto uni_rsrc = [&](const void *base, unsigned bytes) {
+    const uint64_t hb = (uint64_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)hb);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+  };
+  const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
+  const float *dh_b = dh + (size_t)b * C * L, *ds_b = dskip + (size_t)b * C * L;
+  const __amdgpu_buffer_rsrc_t w2rs = uni_rsrc(reinterpret_cast<const char *>(w2t) + (size_t)wave * (4 * 8 * FRB_), 4 * 8 * FRB_);
+  const __amdgpu_buffer_rsrc_t frs = uni_rsrc(reinterpret_cast<const char *>(fac) + (size_t)b * ((size_t)ntiles * 131072u), (unsigned)ntiles * 131072u);
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  auto load_a2 = [&](int step) {                                 // k-step `step` of 32
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(w2rs, lane16, step * FRB_, 0));
+  };
+  bf16x8 a2[4];
+  a2[0] = load_a2(0);
+  a2[1] = load_a2(1);
+  a2[2] = load_a2(2);
+  // operand: chunk = 128 rows of [dh'; dskip] = 8 k-steps; staging thread = (column sj, 32 rows 32 sq ..)
+  const int sj = tid & 127, sq = tid >> 7;
+  const int ts = t0 + sj;
+  const unsigned zv = ts < L ? ((unsigned)ts + (unsigned)(32 * sq) * (unsigned)L) * 4u : 0x80000000u;
+  float zr[32];
+  auto issue_z = [&](int kc) {                                   // chunks 0, 1: dh' rows, 2, 3: dskip rows
+    const __amdgpu_buffer_rsrc_t rs = uni_rsrc(kc < 2 ? dh_b : ds_b, clip_bytes);
+#pragma unroll
+    for (int i = 0; i < 32; i++) zr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zv, ((kc & 1) * 128 + i) * L * 4, 0));
+  };
+  auto store_z = [&](__bf16 *dst) {
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = zr[8 * o + i];
+      *reinterpret_cast<bf16x8 *>(dst + sj * ZSB2_ + 32 * sq + 8 * o) = cvt8(v);
+    }
+  };
+  issue_z(0);
+  // the factors this lane wrote in the forward pass: [tile][wave][column tile][q][lane] x 16 bytes; in flight under the whole GEMM
+  u32x4b fq[4][4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      fq[ct][q] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(frs, lane16, ((ti * 8 + wave) * 16 + ct * 4 + q) * 1024, 2));
+
+  f32x16 accg[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) accg[ct][r] = 0.f;
+  store_z(lds);
+  __syncthreads();
+#pragma unroll 1
+  for (int kc = 0; kc < 4; kc++) {
+    const __bf16 *zb = lds + (kc & 1) * ZB + j * ZSB2_ + 8 * hh;
+    if (kc + 1 < 4) issue_z(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      const int nx = kc * 8 + ks + 3;
+      a2[(ks + 3) & 3] = load_a2(nx < 32 ? nx : 31);
+      bf16x8 bq[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(zb + 32 * ct * ZSB2_ + 16 * ks);
+#pragma unroll
+      for (int ct = 0; ct < 4; ct++) accg[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 3], bq[ct], accg[ct], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kc + 1 < 4) store_z(lds + ((kc + 1) & 1) * ZB);
+    __syncthreads();
+  }
+
+  // ---- epilogue: dy = factor . dg into the tile image [column][2C] (bf16), then out as whole 1 KB sample rows
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int c0 = 32 * wave + 8 * q + 4 * hh;
+      // (the WHOLE 16-byte vector is re-typed, then indexed: an element-wise bit_cast of the buffer-load builtin's vector is mis-folded to a splat)
+      const f32x8 f = __builtin_convertvector(__builtin_bit_cast(f16x8, fq[ct][q]), f32x8);
+      float vt[4], vs[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        vt[e] = accg[ct][4 * q + e] * f[2 * e];
+        vs[e] = accg[ct][4 * q + e] * f[2 * e + 1];
+      }
+      const f32x4 ft = {vt[0], vt[1], vt[2], vt[3]}, fs = {vs[0], vs[1], vs[2], vs[3]};
+      __bf16 *row = lds + (32 * ct + j) * DSB_;
+      *reinterpret_cast<bf16x4 *>(row + c0) = __builtin_convertvector(ft, bf16x4);
+      *reinterpret_cast<bf16x4 *>(row + C + c0) = __builtin_convertvector(fs, bf16x4);
+    }
+  __syncthreads();
+  {
+    const __amdgpu_buffer_rsrc_t ors = uni_rsrc(dy + (size_t)b * L * 2 * C, (unsigned)L * 2u * C * 2u);
+    const int col = tid >> 2, part = tid & 3;                      // a column's 1 KB row leaves as 4 x 256 B
+    const int t = t0 + col;
+    const unsigned off = t < L ? (unsigned)t * 1024u + (unsigned)part * 256u : 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4b *>(lds + col * DSB_ + 128 * part + 8 * i), ors, off + 16u * i, 0, 0);
+  }
+}
+
 #ifdef AP_TOOLS
 __device__ unsigned long long *g_bwdb_stamp = nullptr;           // tools/clock_bwd_bf16.py: [workgroup][2] = (s_memtime, s_memrealtime) ticks around K2's chunk loop
 #endif
@@ -470,6 +596,26 @@ int launch_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *hin, const flo
   return 0;
 }
 
+// the same gradient from the gate factors the forward pass kept (ap_resblock_fwd_gate_save): no recomputation of the dilated conv
+int launch_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *fac, const float *dhp, const float *dskip, void *dy, float *dhin, int B,
+                                   int L, hipStream_t st) {
+  if (!resblock_bwd_bf16_serves(ctx, B, L)) {
+    set_error("ap_resblock_bwd_bf16_saved: built for AP_PREC_BF16 with res = skip = 256 channels and clips below 2^20 samples");
+    return -22;
+  }
+  if (!ctx->bwd_ready) {
+    set_error("ap_resblock_bwd_bf16_saved: the backward weight images are not built (ap_ctx_prepare_backward after every ap_ctx_load_wavenet)");
+    return -22;
+  }
+  const __bf16 *p = (const __bf16 *)ctx->slab_bb + (size_t)layer * (BW_W2T_ + BW_W1B_);
+  const int d = 1 << (layer % ctx->cfg.dilation_cycle);
+  const int nt = (L + 63) / 64, nt4 = (L + 127) / 128;
+  resblock_bwd_gate_fac_bf16_kernel<<<(unsigned)(B * nt4), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt4);
+  resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W2T_, L, d, nt);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
 // This context's two bf16 backward weight images (47 MB): allocation + pack + a host synchronisation, published when complete.
 int prepare_bwd_bf16(ap_ctx *ctx, hipStream_t st) {
   if (ctx->bwd_ready) return 0;
@@ -496,6 +642,14 @@ extern "C" int ap_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *h_in, c
   if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { ap::set_error("ap_resblock_bwd_bf16: layer=%d B=%d L=%d", layer, B, L); return -22; }
   if (dh_in == dh_out) { ap::set_error("ap_resblock_bwd_bf16: dh_in must not alias dh_out"); return -22; }
   return ap::launch_resblock_bwd_bf16(ctx, layer, h_in, part_t_layer, dh_out, dskip, dy_scratch, dh_in, B, L, (hipStream_t)stream);
+}
+
+extern "C" int ap_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *gate_factors, const float *dh_out, const float *dskip,
+                                          void *dy_scratch, float *dh_in, int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !gate_factors || !dh_out || !dskip || !dy_scratch || !dh_in) { ap::set_error("ap_resblock_bwd_bf16_saved: not loaded / null"); return -22; }
+  if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { ap::set_error("ap_resblock_bwd_bf16_saved: layer=%d B=%d L=%d", layer, B, L); return -22; }
+  if (dh_in == dh_out) { ap::set_error("ap_resblock_bwd_bf16_saved: dh_in must not alias dh_out"); return -22; }
+  return ap::launch_resblock_bwd_bf16_saved(ctx, layer, gate_factors, dh_out, dskip, dy_scratch, dh_in, B, L, (hipStream_t)stream);
 }
 
 extern "C" int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L) { return ctx && ap::resblock_bwd_bf16_serves(ctx, B, L) ? 1 : 0; }

@@ -41,6 +41,7 @@ class EpsGrad:
         self.net = net
         self._key = None
         self._gimg = None               # bf16 mode: the group's gate images of forward_save, one buffer reused by every link
+        self.keep_gate_factors = True   # bf16 mode: keep the gate's derivative factors in the forward pass (False: recompute the dilated conv in the backward)
         self.fused_bf16 = True          # tools/check_bwd_bf16.py turns it off to time / compare the composed fp32 backward in bf16 mode
 
     # ---- weights ---------------------------------------------------------------------------------------
@@ -113,16 +114,25 @@ class EpsGrad:
         eng = self._prepare()
         B, _, L = x.shape
         C_, S_, NL = self.C, self.S, self.NL
-        n = (NL + 1) * B * C_ * L + B * S_ * L + NL * C_ + eng.cfg.embed_dim_out
+        keeps = acts and self._keeps_factors(eng, B, L)
+        n = (3 if keeps else NL + 1) * B * C_ * L + B * S_ * L + NL * C_ + eng.cfg.embed_dim_out   # (kept factors: layer 0's input + a ping-pong pair)
         if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256):
             n += NL * B * 2 * C_ * L
         extra = 0
+        if keeps:
+            extra += NL * int(eng.lib.ap_gate_factor_bytes(B, L))
         G = self._group(eng)
         if G > 0:
             need = min(G, NL) * B * L * C_ * 2
             if self._gimg is None or self._gimg.numel() * 2 < need or self._gimg.device != x.device:
                 extra = need
         return 4 * n + extra
+
+    def _keeps_factors(self, eng, B, L) -> bool:
+        """bf16 mode at the shipped shape: the forward pass keeps the gate's derivative factors (ap_resblock_fwd_gate_save: 16.4 MB per
+        clip-second and layer) and the backward reads them instead of recomputing the dilated conv (ap_resblock_bwd_bf16_saved)."""
+        return bool(self.fused_bf16 and self.keep_gate_factors and self._group(eng) > 0 and
+                    eng.lib.ap_resblock_bwd_bf16_available(eng.ctx, B, L))
 
     def _group(self, eng) -> int:
         """Layers per skip GEMM of forward_save's deferred-skip form (bf16 mode; 0: the fused block per layer)."""
@@ -144,7 +154,11 @@ class EpsGrad:
         C_, S_, NL = self.C, self.S, self.NL
         part = torch.empty(NL * C_ + eng.cfg.embed_dim_out, device=dev)
         N.check(lib.ap_embed(eng.ctx, float(step), N.ptr(part), N.stream()), "ap_embed")
-        hs = torch.empty((NL + 1, B, C_, L), device=dev)
+        keeps = acts and self._keeps_factors(eng, B, L)
+        # with kept gate factors the backward needs no layer input but the first (ap_init_conv_bwd): hs = [h_0, ping, pong]
+        hs = torch.empty((3 if keeps else NL + 1, B, C_, L), device=dev)
+        src = (lambda n: 0 if n == 0 else 1 + ((n - 1) & 1)) if keeps else (lambda n: n)
+        dst = (lambda n: 1 + (n & 1)) if keeps else (lambda n: n + 1)
         skip = torch.empty((B, S_, L), device=dev)
         pre = torch.empty((NL, B, 2 * C_, L), device=dev) if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256) else None
         N.check(lib.ap_init_conv(eng.ctx, N.ptr(x), N.ptr(hs[0]), B, L, N.stream()), "ap_init_conv")
@@ -159,9 +173,16 @@ class EpsGrad:
                 self._gimg = None
                 self._gimg = torch.empty(need, device=dev, dtype=torch.bfloat16)
             gimg = self._gimg[:need].view(min(G, NL), B, L, C_)
+            if keeps:
+                pre = torch.empty((NL, int(lib.ap_gate_factor_bytes(B, L))), device=dev, dtype=torch.uint8)   # (rides in the `pre` slot of `saved`)
             for n0 in range(0, NL, G):
                 nl = min(G, NL - n0)
                 for n in range(n0, n0 + nl):
+                    if pre is not None:
+                        N.check(lib.ap_resblock_fwd_gate_save(eng.ctx, n, N.ptr(hs[src(n)]), N.ptr(part[n * C_:(n + 1) * C_]),
+                                                              N.ptr(hs[dst(n)]) if n + 1 < NL else None, gimg[n - n0].data_ptr(),
+                                                              pre[n].data_ptr(), B, L, N.stream()), "ap_resblock_fwd_gate_save")
+                        continue
                     N.check(lib.ap_resblock_fwd_gate(eng.ctx, n, N.ptr(hs[n]), N.ptr(part[n * C_:(n + 1) * C_]),
                                                      N.ptr(hs[n + 1]) if n + 1 < NL else None, gimg[n - n0].data_ptr(), B, L, N.stream()),
                             "ap_resblock_fwd_gate")
@@ -206,6 +227,17 @@ class EpsGrad:
             for n in range(NL - 1, -1, -1):
                 N.check(lib.ap_resblock_bwd(eng.ctx, n, N.ptr(dh), N.ptr(dskip), N.ptr(pre[n]), N.ptr(dy), N.ptr(dh2), B, L, st),
                         "ap_resblock_bwd")
+                dh, dh2 = dh2, dh
+            dx = torch.empty((B, 1, L), device=dev)
+            N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")
+            return dx
+        if pre is not None and pre.dtype == torch.uint8:
+            # bf16 mode with kept gate factors: dg = W2^T [dh'; dskip], dy = factor . dg, then the transposed dilated conv -- no recomputation
+            dy = torch.empty((B, L, 2 * C_), device=dev, dtype=torch.bfloat16)
+            dh2 = torch.empty_like(dh)
+            for n in range(NL - 1, -1, -1):
+                N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, n, pre[n].data_ptr(), N.ptr(dh), N.ptr(dskip), dy.data_ptr(), N.ptr(dh2), B, L, st),
+                        "ap_resblock_bwd_bf16_saved")
                 dh, dh2 = dh2, dh
             dx = torch.empty((B, 1, L), device=dev)
             N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")

@@ -259,6 +259,18 @@ int ap_resblock_bwd_available(ap_ctx *ctx, int B, int L);
 int ap_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, const float *dh_out, const float *dskip,
                          void *dy_scratch, float *dh_in, int B, int L, void *stream);
 int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L);
+/* The gradient pass can skip the recomputation: ap_resblock_fwd_gate_save is ap_resblock_fwd_gate (bit-identical h_out and g_image)
+ * that also keeps the gate's two derivative factors sg (1 - th^2), th sg (1 - sg) as an fp16 pair per (channel, sample) in
+ * gate_factors -- an opaque image of ap_gate_factor_bytes(B, L) bytes (128 KB per clip and 128-sample tile, in the block kernel's own
+ * accumulator order) -- and ap_resblock_bwd_bf16_saved is ap_resblock_bwd_bf16 that reads them instead of h_in / part_t:
+ *   dy = factors . ([W_res sqrt(1/2); W_skip]^T [dh_out; dskip]);   dh_in = sqrt(1/2) dh_out + DilConv^T(dy).
+ * (|factor| <= 1 at 11 significant bits; dy is rounded to bf16 behind it either way.)  The reference's autograd keeps its
+ * activations too (white_box_attack.py:392,437-439). */
+size_t ap_gate_factor_bytes(int B, int L);
+int ap_resblock_fwd_gate_save(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out, void *g_image,
+                              void *gate_factors, int B, int L, void *stream);
+int ap_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *gate_factors, const float *dh_out, const float *dskip,
+                               void *dy_scratch, float *dh_in, int B, int L, void *stream);
 
 int ap_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out,
                     float ca, float cb, float cs, const float *z, uint64_t seed, uint32_t draw,

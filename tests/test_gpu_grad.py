@@ -447,6 +447,7 @@ def test_fused_block_backward_matches_autograd_through_the_oracle(dev, L, layer)
     lib = eng.lib
     B, C_, d = 2, 256, 2 ** (layer % 12)
     assert lib.ap_resblock_bwd_available(eng.ctx, B, L) == 1
+    N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))      # the backward's own weight images: built once per load, never by a launch
     h = torch.from_numpy(synth.uniform(f"gh/{L}", (B, C_, L), 1, -1.5, 1.5))
     gh = torch.from_numpy(synth.uniform(f"gg/{L}", (B, C_, L), 2, -1.0, 1.0))
     gs = torch.from_numpy(synth.uniform(f"gs/{L}", (B, C_, L), 3, -1.0, 1.0))
@@ -500,6 +501,7 @@ def test_bf16_block_backward_matches_autograd_through_the_bf16_oracle(dev, L, la
     lib = eng.lib
     B, C_, d = 2, 256, 2 ** (layer % 12)
     assert lib.ap_resblock_bwd_bf16_available(eng.ctx, B, L) == 1
+    N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
     h = torch.from_numpy(synth.uniform(f"gh/{L}", (B, C_, L), 1, -1.5, 1.5))
     gh = torch.from_numpy(synth.uniform(f"gg/{L}", (B, C_, L), 2, -1.0, 1.0))
     gs = torch.from_numpy(synth.uniform(f"gs/{L}", (B, C_, L), 3, -1.0, 1.0))
@@ -521,10 +523,33 @@ def test_bf16_block_backward_matches_autograd_through_the_bf16_oracle(dev, L, la
     dy_ok(); dh_ok()
     N.check(lib.ap_resblock_bwd_bf16(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ghd), N.ptr(gsd), dy.data_ptr(), N.ptr(dh_in), B, L, N.stream()))
     assert torch.equal(got, dh_in.cpu())                         # run to run bit-identical
+    # the same gradient from KEPT gate factors (round 6): ap_resblock_fwd_gate_save writes them beside a bit-identical h' / g image,
+    # ap_resblock_bwd_bf16_saved reads them instead of recomputing the dilated conv -- held to the same bars, and close to the
+    # recomputing form (the factors are the forward's fast-exp gate quantities at fp16 instead of a compensated exp at fp32)
+    ho, ho2 = torch.empty_like(hd), torch.empty_like(hd)
+    gi, gi2 = (torch.empty((B, L, C_), dtype=torch.bfloat16, device=dev) for _ in range(2))
+    fac = torch.zeros(lib.ap_gate_factor_bytes(B, L), dtype=torch.uint8, device=dev)
+    N.check(lib.ap_resblock_fwd_gate_save(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ho), gi.data_ptr(), fac.data_ptr(), B, L, N.stream()))
+    N.check(lib.ap_resblock_fwd_gate(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), N.ptr(ho2), gi2.data_ptr(), B, L, N.stream()))
+    assert torch.equal(ho, ho2) and torch.equal(gi.view(torch.int16), gi2.view(torch.int16))
+    _, dy2, dy2_ok = _guarded((B, L, 2 * C_), dev, torch.bfloat16, 0.0)
+    _, dh2, dh2_ok = _guarded(hd.shape, dev)
+    N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, layer, fac.data_ptr(), N.ptr(ghd), N.ptr(gsd), dy2.data_ptr(), N.ptr(dh2), B, L, N.stream()))
+    got2 = dh2.cpu()
+    assert torch.isfinite(got2).all()
+    assert _cos(got2, g_ref) >= 0.999, (_cos(got2, g_ref),)
+    assert rel_err(got2.numpy(), g_ref.numpy()) <= 2e-2
+    assert rel_err(got2.numpy(), got.numpy()) <= 5e-3
+    dy2_ok(); dh2_ok()
+    gi3 = torch.empty_like(gi)                                   # h_out = NULL (the net's last layer): same g image, same factors
+    fac3 = torch.zeros_like(fac)
+    N.check(lib.ap_resblock_fwd_gate_save(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), None, gi3.data_ptr(), fac3.data_ptr(), B, L, N.stream()))
+    assert torch.equal(gi3.view(torch.int16), gi.view(torch.int16)) and torch.equal(fac3, fac)
 
 
 def test_bf16_eps_vjp_runs_on_the_bf16_backward_and_matches_the_bf16_oracle(dev):
-    """The whole eps VJP in bf16 mode (forward: the bf16 block keeping layer inputs; backward: ap_resblock_bwd_bf16 per layer).
+    """The whole eps VJP in bf16 mode, both forms: the forward keeping the gate's derivative factors + ap_resblock_bwd_bf16_saved per
+    layer (default since round 6), and the forward keeping layer inputs + ap_resblock_bwd_bf16 (the dilated conv recomputed).
     (1) Against the composed fp32 backward on the SAME stored layer inputs -- the backward kernels' own error through six layers:
     cosine >= 0.9999, max deviation <= 2e-2 of the largest entry (the per-block bar).
     (2) Against autograd through the bf16-emulating oracle network: cosine >= 0.999.  The largest deviation is NOT held to 2e-2
@@ -547,13 +572,54 @@ def test_bf16_eps_vjp_runs_on_the_bf16_backward_and_matches_the_bf16_oracle(dev)
         eps_ref = O.eps_net(w, cfg, xr, torch.full((B, 1), step), bf16_operands=bf)
         (refs[bf],) = torch.autograd.grad(eps_ref, xr, v)
     eg = EpsGrad(net)
-    eps, saved = eg.forward_save(x.to(dev), step)
-    assert saved[3] is None                                      # bf16 mode keeps layer inputs only
-    assert torch.equal(eps, eg.eps_only(x.to(dev), step))        # the saving forward runs the chain's own deferred-skip form: same eps, bit for bit
-    g = eg.backward(saved, v.to(dev)).cpu()
+    xd, vd = x.to(dev), v.to(dev)
+    # round 6: by default the forward pass keeps the gate's derivative factors (an opaque uint8 image per layer) and only the
+    # first layer's input; the backward reads them instead of recomputing the dilated conv
+    eps, saved = eg.forward_save(xd, step)
+    assert saved[3] is not None and saved[3].dtype == torch.uint8 and saved[0].shape[0] == 3
+    assert torch.equal(eps, eg.eps_only(xd, step))               # the saving forward runs the chain's own deferred-skip form: same eps, bit for bit
+    g_kept = eg.backward(saved, vd).cpu()
+    eg.keep_gate_factors = False                                 # the round-5 form: every layer's input kept, the dilated conv recomputed
+    eps2, saved2 = eg.forward_save(xd, step)
+    assert saved2[3] is None and torch.equal(eps2, eps)
+    g = eg.backward(saved2, vd).cpu()
     eg.fused_bf16 = False
-    g_fp32 = eg.backward(saved, v.to(dev)).cpu()                 # same layer inputs, fp32 GEMMs
-    assert _cos(g, g_fp32) >= 0.9999 and rel_err(g.numpy(), g_fp32.numpy()) <= 2e-2, (_cos(g, g_fp32), rel_err(g.numpy(), g_fp32.numpy()))
+    g_fp32 = eg.backward(saved2, vd).cpu()                       # same layer inputs, fp32 GEMMs
     l2 = lambda a, b: float((a - b).norm() / b.norm())
-    assert _cos(g, refs[True]) >= 0.999, _cos(g, refs[True])
-    assert l2(g, refs[True]) <= l2(refs[False], refs[True]), (l2(g, refs[True]), l2(refs[False], refs[True]))
+    for name, gg in (("kept factors", g_kept), ("recomputing", g)):
+        assert _cos(gg, g_fp32) >= 0.9999 and rel_err(gg.numpy(), g_fp32.numpy()) <= 2e-2, (name, _cos(gg, g_fp32), rel_err(gg.numpy(), g_fp32.numpy()))
+        assert _cos(gg, refs[True]) >= 0.999, (name, _cos(gg, refs[True]))
+        assert l2(gg, refs[True]) <= l2(refs[False], refs[True]), (name, l2(gg, refs[True]), l2(refs[False], refs[True]))
+
+
+def test_backward_launches_refuse_to_run_before_the_images_are_built(dev):
+    """the backward launch functions allocate nothing (include/audiopure.h: device memory is allocated in
+    ap_ctx_load_wavenet / ap_ctx_prepare_backward / ap_m5_create only; launch functions are hipGraph-capturable).  Before
+    ap_ctx_prepare_backward -- and again after the weights are re-loaded -- they return -22 and say what to call."""
+    from audiopure_amd import _native as N
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    for mode, fn in (("f32", "ap_resblock_bwd"), ("bf16", "ap_resblock_bwd_bf16")):
+        net, _ = _net(cfg, dev, seed=3)
+        net.set_precision(mode)
+        eng = net.engine()
+        lib = eng.lib
+        B, L = 1, 256
+        t = torch.zeros((B, 512, L), device=dev)
+        h = torch.zeros((B, 256, L), device=dev)
+        pt = torch.zeros(256, device=dev)
+        o = torch.empty_like(h)
+
+        def call():
+            if mode == "f32":
+                return lib.ap_resblock_bwd(eng.ctx, 0, N.ptr(h), N.ptr(h), N.ptr(t), N.ptr(t), N.ptr(o), B, L, N.stream())
+            return lib.ap_resblock_bwd_bf16(eng.ctx, 0, N.ptr(h), N.ptr(pt), N.ptr(h), N.ptr(h), t.data_ptr(), N.ptr(o), B, L, N.stream())
+        assert call() == -22 and b"ap_ctx_prepare_backward" in lib.ap_last_error()
+        N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
+        N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))      # a second call is a no-op
+        assert call() == 0
+        net.init_conv[0].conv.bias.data.add_(1.0)                      # parameters changed: engine() re-loads, the images are stale
+        eng2 = net.engine()
+        assert eng2 is eng
+        assert call() == -22
+        N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
+        assert call() == 0

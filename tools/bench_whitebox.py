@@ -1,5 +1,5 @@
 """one white-box gradient step through the purifier (RevDiffWave Euler chain, shipped config):
-forward + backward w.r.t. the audio.  python tools/bench_whitebox.py [B] [t*] [f32|f32s]"""
+forward + backward w.r.t. the audio.  python tools/bench_whitebox.py [B] [t*] [f32|f32s|bf16]"""
 import sys, os, time, types, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audiopure_amd import synth
@@ -29,7 +29,10 @@ g = step(); torch.cuda.synchronize()
 t0 = time.perf_counter(); R = 2
 for _ in range(R): g = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / R
-with torch.no_grad():
-    t1 = time.perf_counter(); runner(x); torch.cuda.synchronize(); tf = time.perf_counter() - t1
+with torch.no_grad():                                           # (warm first: the no-grad chain's first call captures its graph / sizes its workspace)
+    runner(x); torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(R): runner(x)
+    torch.cuda.synchronize(); tf = (time.perf_counter() - t1) / R
 print(f"white-box gradient step [{mode}]: B={B} t*={t_star}: {dt*1e3:.1f} ms (forward + backward) = {B/dt:.2f} clips/s; "
       f"forward-only purify {tf*1e3:.1f} ms; grad finite={bool(torch.isfinite(g).all())} |g|max={float(g.abs().max()):.3e}")

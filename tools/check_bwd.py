@@ -27,6 +27,7 @@ def main():
     w = O.fold_state_dict(sd)
     eng = net.engine()
     lib = eng.lib
+    N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
     for L, layer in [(1100, 0), (2048, 5), (1000, 11), (130, 3), (16000, 6)]:
         B, C, d = 2, 256, 2 ** layer
         p = f"residual_layer.residual_blocks.{layer}"

@@ -24,6 +24,7 @@ def net_(cfg, seed):
 cfg = synth.mini_wavenet_config(256, 12, 12)
 net, w = net_(cfg, 3)
 eng = net.engine(); lib = eng.lib
+N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
 B, C_ = 2, 256
 for L, layer in ((1100, 0), (2048, 5), (16000, 6)):
     d = 2 ** layer

@@ -598,9 +598,9 @@ unsigned long long *g_trace_bf16 = nullptr;   // ap_debug_trace: device buffer o
 #endif
 
 int launch_resblock_bf16(ap_ctx *ctx, int layer, const float *hin, const float *pt, float *hout, float *skip,
-                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub, void *gout) {
+                         int accumulate, int B, int L, hipStream_t st, const UbArgs *ub, void *gout, void *fout) {
   const int C = ctx->C, S = ctx->S;
-  if (ub || gout) return launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout);
+  if (ub || gout) return launch_resblock_bf16p(ctx, layer, hin, pt, hout, skip, accumulate, B, L, st, ub, gout, fout);
   if (C != 256) {
     set_error("AP_PREC_BF16 is built for res_channels = 256 only (got %d)", C);
     return -22;

@@ -35,6 +35,7 @@ for i in range(cases):
     res = {}
     # fp32: the saving forward keeps the pre-gate activations, then ap_resblock_bwd
     e = nets["f32"].engine()
+    N.check(e.lib.ap_ctx_prepare_backward(e.ctx, N.stream()))
     ho, sk, pre = torch.empty_like(h), torch.zeros_like(h), torch.empty(B, 512, L, device=dev)
     N.check(e.lib.ap_resblock_fwd_save(e.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho), N.ptr(sk), N.ptr(pre), 0, B, L, N.stream()))
     outs = []
@@ -46,6 +47,7 @@ for i in range(cases):
     if not torch.equal(outs[0], outs[1]): print("NONDETERMINISTIC fp32", tag); bad += 1
     res["f32"] = outs[0]
     e = nets["bf16"].engine()
+    N.check(e.lib.ap_ctx_prepare_backward(e.ctx, N.stream()))
     outs = []
     for rep in range(2):
         yb, dy, ny = guarded((B, L, 512), torch.bfloat16); db, dh, nd = guarded((B, 256, L))
@@ -54,6 +56,18 @@ for i in range(cases):
         outs.append(dh.clone())
     if not torch.equal(outs[0], outs[1]): print("NONDETERMINISTIC bf16", tag); bad += 1
     res["bf16"] = outs[0]
+    # bf16 from kept gate factors: ap_resblock_fwd_gate_save (h' / g image bit-identical to ap_resblock_fwd_gate) + ap_resblock_bwd_bf16_saved
+    ho1, ho2 = torch.empty_like(h), torch.empty_like(h)
+    g1, g2 = (torch.empty((B, L, 256), dtype=torch.bfloat16, device=dev) for _ in range(2))
+    fac = torch.empty(e.lib.ap_gate_factor_bytes(B, L), dtype=torch.uint8, device=dev)
+    N.check(e.lib.ap_resblock_fwd_gate_save(e.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho1), g1.data_ptr(), fac.data_ptr(), B, L, N.stream()))
+    N.check(e.lib.ap_resblock_fwd_gate(e.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho2), g2.data_ptr(), B, L, N.stream()))
+    if not (torch.equal(ho1, ho2) and torch.equal(g1.view(torch.int16), g2.view(torch.int16))): print("SAVE FORWARD DIFFERS", tag); bad += 1
+    yb, dy, ny = guarded((B, L, 512), torch.bfloat16); db, dh, nd = guarded((B, 256, L))
+    N.check(e.lib.ap_resblock_bwd_bf16_saved(e.ctx, layer, fac.data_ptr(), N.ptr(gh), N.ptr(gs), dy.data_ptr(), N.ptr(dh), B, L, N.stream()))
+    if not (intact(yb, ny) and intact(db, nd)): print("OUT-OF-BOUNDS WRITE bf16 saved", tag); bad += 1
+    es = float((dh - res["bf16"]).abs().max() / res["bf16"].abs().max())
+    if not es < 1e-2: print("SAVED-FACTOR FORM FAR FROM THE RECOMPUTING ONE", es, tag); bad += 1
     for m, t in res.items():
         if not bool(torch.isfinite(t).all()): print("NONFINITE", m, tag); bad += 1
     err = float((res["bf16"] - res["f32"]).abs().max() / res["f32"].abs().max())

@@ -14,6 +14,7 @@ net = WaveNet_Speech_Commands(**cfg)
 net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(cfg, 3).items()})
 net = net.to(dev).set_precision("bf16")
 eng = net.engine(); lib = eng.lib
+N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
 h = torch.randn(B, 256, L, device=dev); gh = torch.randn_like(h); gs = torch.randn_like(h); out = torch.empty_like(h)
 pt = torch.randn(256, device=dev)
 dy = torch.empty((B, L, 512), device=dev, dtype=torch.bfloat16)
