@@ -68,7 +68,8 @@ SIGNATURES = {
     "ap_resblock_bwd_bf16_available": (_i, [_vp, _i, _i]),
     "ap_gate_factor_bytes": (_sz, [_i, _i]),
     "ap_resblock_fwd_gate_save": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _vp, _i, _i, _vp]),
-    "ap_resblock_bwd_bf16_saved": (_i, [_vp, _i, _vp, _fp, _fp, _vp, _fp, _i, _i, _vp]),
+    "ap_resblock_bwd_bf16_saved": (_i, [_vp, _i, _vp, _fp, _vp, _i, _vp, _fp, _i, _i, _vp]),
+    "ap_bwd_bf16_rows_image": (_i, [_fp, _vp, _i, _i, _i, _vp]),
     "ap_resblock_fwd_gate": (_i, [_vp, _i, _fp, _fp, _fp, _vp, _i, _i, _vp]),
     "ap_skip_gemm": (_i, [_vp, _i, _i, _vp, _fp, _i, _i, _i, _vp]),
     "ap_ctx_set_skip_group": (_i, [_vp, _i]),

@@ -326,7 +326,10 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_bf16_kernel(
 // transcendental: dg = [sqrt(1/2) W_res; W_skip]^T [dh'; dskip], dy = factor . dg.  Same tile / wave / lane / register geometry as the
 // forward's gate phase: lane l of wave w reads back, per (column tile, q), the 16 bytes it wrote.
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const float *__restrict__ dh, const float *__restrict__ dskip,
+// DSI: dskip -- the same tensor for all 36 layers of a link -- arrives as a bf16 image [clip][sample][S] (ap_bwd_bf16_rows_image, once
+// per link) instead of fp32 rows: its staging is four 16-byte loads and stores per thread and chunk, no convert, half the bytes.
+template <bool DSI>
+__global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const float *__restrict__ dh, const void *__restrict__ dskip,
                                                                          const void *__restrict__ fac, __bf16 *__restrict__ dy,
                                                                          const __bf16 *__restrict__ w2t, int L, int ntiles) {
   constexpr int C = QC_;
@@ -347,7 +350,8 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
   };
   const unsigned clip_bytes = (unsigned)C * (unsigned)L * 4u;
-  const float *dh_b = dh + (size_t)b * C * L, *ds_b = dskip + (size_t)b * C * L;
+  const float *dh_b = dh + (size_t)b * C * L, *ds_b = DSI ? nullptr : static_cast<const float *>(dskip) + (size_t)b * C * L;
+  const __amdgpu_buffer_rsrc_t dsirs = uni_rsrc(static_cast<const char *>(dskip) + (size_t)b * ((size_t)L * C * 2), (unsigned)L * C * 2u);   // DSI: [sample][S] bf16
   const __amdgpu_buffer_rsrc_t w2rs = uni_rsrc(reinterpret_cast<const char *>(w2t) + (size_t)wave * (4 * 8 * FRB_), 4 * 8 * FRB_);
   const __amdgpu_buffer_rsrc_t frs = uni_rsrc(reinterpret_cast<const char *>(fac) + (size_t)b * ((size_t)ntiles * 131072u), (unsigned)ntiles * 131072u);
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -364,12 +368,24 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
   const int ts = t0 + sj;
   const unsigned zv = ts < L ? ((unsigned)ts + (unsigned)(32 * sq) * (unsigned)L) * 4u : 0x80000000u;
   float zr[32];
+  u32x4b zq[4];
+  const unsigned ziv = ts < L ? (unsigned)ts * (unsigned)(C * 2) + (unsigned)(64 * sq) : 0x80000000u;   // DSI: this thread's 32 channels of the sample's row
   auto issue_z = [&](int kc) {                                   // chunks 0, 1: dh' rows, 2, 3: dskip rows
+    if (DSI && kc >= 2) {
+#pragma unroll
+      for (int o = 0; o < 4; o++) zq[o] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(dsirs, ziv + 16u * o, (kc & 1) * 256, 0));
+      return;
+    }
     const __amdgpu_buffer_rsrc_t rs = uni_rsrc(kc < 2 ? dh_b : ds_b, clip_bytes);
 #pragma unroll
     for (int i = 0; i < 32; i++) zr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zv, ((kc & 1) * 128 + i) * L * 4, 0));
   };
-  auto store_z = [&](__bf16 *dst) {
+  auto store_z = [&](__bf16 *dst, int kc) {
+    if (DSI && kc >= 2) {
+#pragma unroll
+      for (int o = 0; o < 4; o++) *reinterpret_cast<u32x4b *>(dst + sj * ZSB2_ + 32 * sq + 8 * o) = zq[o];
+      return;
+    }
 #pragma unroll
     for (int o = 0; o < 4; o++) {
       float v[8];
@@ -392,7 +408,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
   for (int ct = 0; ct < 4; ct++)
 #pragma unroll
     for (int r = 0; r < 16; r++) accg[ct][r] = 0.f;
-  store_z(lds);
+  store_z(lds, 0);
   __syncthreads();
 #pragma unroll 1
   for (int kc = 0; kc < 4; kc++) {
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
       for (int ct = 0; ct < 4; ct++) accg[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 3], bq[ct], accg[ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (kc + 1 < 4) store_z(lds + ((kc + 1) & 1) * ZB);
+    if (kc + 1 < 4) store_z(lds + ((kc + 1) & 1) * ZB, kc + 1);
     __syncthreads();
   }
 
@@ -596,9 +612,38 @@ int launch_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *hin, const flo
   return 0;
 }
 
-// the same gradient from the gate factors the forward pass kept (ap_resblock_fwd_gate_save): no recomputation of the dilated conv
-int launch_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *fac, const float *dhp, const float *dskip, void *dy, float *dhin, int B,
-                                   int L, hipStream_t st) {
+// rows [B][C][L] fp32 -> image [B][L][C] bf16 (RNE), C = 256: a 64-sample x 256-channel tile per workgroup through LDS
+__global__ __launch_bounds__(256) void rows_image_bf16_kernel(const float *__restrict__ x, __bf16 *__restrict__ img, int L, int ntiles) {
+  constexpr int C = QC_;
+  __shared__ float tile[64][C + 1];
+  const int b = blockIdx.x / ntiles, t0 = (blockIdx.x % ntiles) * 64;
+  const int tid = threadIdx.x;
+  const float *xb = x + (size_t)b * C * L;
+#pragma unroll 4
+  for (int i = 0; i < 64; i++) {                                 // thread = (sample tid & 63, channel i * 4 + (tid >> 6)): coalesced along the samples
+    const int c = 4 * i + (tid >> 6), t = t0 + (tid & 63);
+    tile[tid & 63][c] = t < L ? xb[(size_t)c * L + t] : 0.f;
+  }
+  __syncthreads();
+  __bf16 *ib = img + (size_t)b * L * C;
+#pragma unroll 4
+  for (int i = 0; i < 64; i++) {                                 // thread = channel tid of sample i: a 512-byte row per step
+    const int t = t0 + i;
+    if (t < L) ib[(size_t)t * C + tid] = (__bf16)tile[i][tid];
+  }
+}
+
+int launch_rows_image_bf16(const float *x, void *img, int B, int L, hipStream_t st) {
+  const int nt = (L + 63) / 64;
+  rows_image_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>(x, (__bf16 *)img, L, nt);
+  AP_HIP(hipGetLastError());
+  return 0;
+}
+
+// the same gradient from the gate factors the forward pass kept (ap_resblock_fwd_gate_save): no recomputation of the dilated conv.
+// dskip_is_image: dskip is the bf16 image [B][L][S] of ap_bwd_bf16_rows_image instead of fp32 rows [B][S][L]
+int launch_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *fac, const float *dhp, const void *dskip, int dskip_is_image, void *dy,
+                                   float *dhin, int B, int L, hipStream_t st) {
   if (!resblock_bwd_bf16_serves(ctx, B, L)) {
     set_error("ap_resblock_bwd_bf16_saved: built for AP_PREC_BF16 with res = skip = 256 channels and clips below 2^20 samples");
     return -22;
@@ -610,7 +655,12 @@ int launch_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *fac, cons
   const __bf16 *p = (const __bf16 *)ctx->slab_bb + (size_t)layer * (BW_W2T_ + BW_W1B_);
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const int nt = (L + 63) / 64, nt4 = (L + 127) / 128;
-  resblock_bwd_gate_fac_bf16_kernel<<<(unsigned)(B * nt4), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt4);
+  if (dskip_is_image) {
+    if ((size_t)L * QC_ * 2 >= ((size_t)1 << 31)) { set_error("ap_resblock_bwd_bf16_saved: clip too long for the bf16 dskip image"); return -22; }
+    resblock_bwd_gate_fac_bf16_kernel<true><<<(unsigned)(B * nt4), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt4);
+  } else {
+    resblock_bwd_gate_fac_bf16_kernel<false><<<(unsigned)(B * nt4), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt4);
+  }
   resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W2T_, L, d, nt);
   AP_HIP(hipGetLastError());
   return 0;
@@ -644,12 +694,18 @@ extern "C" int ap_resblock_bwd_bf16(ap_ctx *ctx, int layer, const float *h_in, c
   return ap::launch_resblock_bwd_bf16(ctx, layer, h_in, part_t_layer, dh_out, dskip, dy_scratch, dh_in, B, L, (hipStream_t)stream);
 }
 
-extern "C" int ap_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *gate_factors, const float *dh_out, const float *dskip,
-                                          void *dy_scratch, float *dh_in, int B, int L, void *stream) {
+extern "C" int ap_bwd_bf16_rows_image(const float *rows, void *image, int B, int C, int L, void *stream) {
+  if (!rows || !image || B < 1 || L < 1) { ap::set_error("ap_bwd_bf16_rows_image: bad argument"); return -22; }
+  if (C != 256) { ap::set_error("ap_bwd_bf16_rows_image: built for 256 channels (got %d)", C); return -22; }
+  return ap::launch_rows_image_bf16(rows, image, B, L, (hipStream_t)stream);
+}
+
+extern "C" int ap_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *gate_factors, const float *dh_out, const void *dskip,
+                                          int dskip_is_image, void *dy_scratch, float *dh_in, int B, int L, void *stream) {
   if (!ctx || !ctx->loaded || !gate_factors || !dh_out || !dskip || !dy_scratch || !dh_in) { ap::set_error("ap_resblock_bwd_bf16_saved: not loaded / null"); return -22; }
   if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { ap::set_error("ap_resblock_bwd_bf16_saved: layer=%d B=%d L=%d", layer, B, L); return -22; }
   if (dh_in == dh_out) { ap::set_error("ap_resblock_bwd_bf16_saved: dh_in must not alias dh_out"); return -22; }
-  return ap::launch_resblock_bwd_bf16_saved(ctx, layer, gate_factors, dh_out, dskip, dy_scratch, dh_in, B, L, (hipStream_t)stream);
+  return ap::launch_resblock_bwd_bf16_saved(ctx, layer, gate_factors, dh_out, dskip, dskip_is_image, dy_scratch, dh_in, B, L, (hipStream_t)stream);
 }
 
 extern "C" int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L) { return ctx && ap::resblock_bwd_bf16_serves(ctx, B, L) ? 1 : 0; }

@@ -99,8 +99,8 @@ class EpsGrad:
         return eng
 
     def _conv(self, lib, x, packed, bias, res, out, B, Cin, L, Cout, kw, pad, dil, flags=0):
-        if self.net._precision == N.AP_PREC_F32_SPLIT:           # follow the network's arithmetic mode
-            flags |= 0x100                                       # AP_CONV_SPLIT
+        if self.net._precision in (N.AP_PREC_F32_SPLIT, N.AP_PREC_BF16):   # follow the network's arithmetic mode: the split GEMM (fp32-class
+            flags |= 0x100                                       # results from the bf16 matrix pipe, AP_CONV_SPLIT) where the forward ran on that pipe too
         fl = flags | _F1D | ((dil << 16) if dil > 1 else 0)
         N.use_conv_workspace(x.device)                           # short clips meet the split-K condition: this device's buffer
         N.check(lib.ap_conv2d_fwd(N.ptr(x), N.ptr(packed), N.ptr(bias), N.ptr(res), N.ptr(out), B, Cin, 1, L, Cout, 1, kw, 1,
@@ -235,8 +235,10 @@ class EpsGrad:
             # bf16 mode with kept gate factors: dg = W2^T [dh'; dskip], dy = factor . dg, then the transposed dilated conv -- no recomputation
             dy = torch.empty((B, L, 2 * C_), device=dev, dtype=torch.bfloat16)
             dh2 = torch.empty_like(dh)
+            dsk = torch.empty((B, L, S_), device=dev, dtype=torch.bfloat16)      # dskip once as the bf16 image every layer's kernel stages
+            N.check(lib.ap_bwd_bf16_rows_image(N.ptr(dskip), dsk.data_ptr(), B, S_, L, st), "ap_bwd_bf16_rows_image")
             for n in range(NL - 1, -1, -1):
-                N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, n, pre[n].data_ptr(), N.ptr(dh), N.ptr(dskip), dy.data_ptr(), N.ptr(dh2), B, L, st),
+                N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, n, pre[n].data_ptr(), N.ptr(dh), dsk.data_ptr(), 1, dy.data_ptr(), N.ptr(dh2), B, L, st),
                         "ap_resblock_bwd_bf16_saved")
                 dh, dh2 = dh2, dh
             dx = torch.empty((B, 1, L), device=dev)

@@ -269,8 +269,12 @@ int ap_resblock_bwd_bf16_available(ap_ctx *ctx, int B, int L);
 size_t ap_gate_factor_bytes(int B, int L);
 int ap_resblock_fwd_gate_save(ap_ctx *ctx, int layer, const float *h_in, const float *part_t_layer, float *h_out, void *g_image,
                               void *gate_factors, int B, int L, void *stream);
-int ap_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *gate_factors, const float *dh_out, const float *dskip,
-                               void *dy_scratch, float *dh_in, int B, int L, void *stream);
+int ap_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *gate_factors, const float *dh_out, const void *dskip,
+                               int dskip_is_image, void *dy_scratch, float *dh_in, int B, int L, void *stream);
+/* dskip is the same tensor for every layer of an evaluation (skip is their sum): with dskip_is_image != 0 it is handed over once as
+ * the bf16 image [B][L][S] ap_bwd_bf16_rows_image makes of the fp32 rows [B][S][L] (C = 256) -- what the kernel's staging would round
+ * it to anyway, at half the bytes per layer and without the convert. */
+int ap_bwd_bf16_rows_image(const float *rows, void *image, int B, int C, int L, void *stream);
 
 int ap_final_affine(ap_ctx *ctx, const float *skip, const float *x, float *eps_out, float *out,
                     float ca, float cb, float cs, const float *z, uint64_t seed, uint32_t draw,

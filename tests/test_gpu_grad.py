@@ -534,13 +534,20 @@ def test_bf16_block_backward_matches_autograd_through_the_bf16_oracle(dev, L, la
     assert torch.equal(ho, ho2) and torch.equal(gi.view(torch.int16), gi2.view(torch.int16))
     _, dy2, dy2_ok = _guarded((B, L, 2 * C_), dev, torch.bfloat16, 0.0)
     _, dh2, dh2_ok = _guarded(hd.shape, dev)
-    N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, layer, fac.data_ptr(), N.ptr(ghd), N.ptr(gsd), dy2.data_ptr(), N.ptr(dh2), B, L, N.stream()))
+    N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, layer, fac.data_ptr(), N.ptr(ghd), N.ptr(gsd), 0, dy2.data_ptr(), N.ptr(dh2), B, L, N.stream()))
     got2 = dh2.cpu()
     assert torch.isfinite(got2).all()
     assert _cos(got2, g_ref) >= 0.999, (_cos(got2, g_ref),)
     assert rel_err(got2.numpy(), g_ref.numpy()) <= 2e-2
     assert rel_err(got2.numpy(), got.numpy()) <= 5e-3
     dy2_ok(); dh2_ok()
+    # dskip handed over once as the bf16 image [B][L][S] (ap_bwd_bf16_rows_image): what the staging rounds it to anyway -> bit-identical
+    dsk = torch.empty((B, L, C_), dtype=torch.bfloat16, device=dev)
+    N.check(lib.ap_bwd_bf16_rows_image(N.ptr(gsd), dsk.data_ptr(), B, C_, L, N.stream()))
+    assert torch.equal(dsk.float().cpu(), gs.to(torch.bfloat16).float().permute(0, 2, 1))
+    dh3 = torch.empty_like(hd)
+    N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, layer, fac.data_ptr(), N.ptr(ghd), dsk.data_ptr(), 1, dy2.data_ptr(), N.ptr(dh3), B, L, N.stream()))
+    assert torch.equal(dh3.cpu(), got2)
     gi3 = torch.empty_like(gi)                                   # h_out = NULL (the net's last layer): same g image, same factors
     fac3 = torch.zeros_like(fac)
     N.check(lib.ap_resblock_fwd_gate_save(eng.ctx, layer, N.ptr(hd), N.ptr(ptd), None, gi3.data_ptr(), fac3.data_ptr(), B, L, N.stream()))
@@ -617,7 +624,8 @@ def test_backward_launches_refuse_to_run_before_the_images_are_built(dev):
         N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
         N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))      # a second call is a no-op
         assert call() == 0
-        net.init_conv[0].conv.bias.data.add_(1.0)                      # parameters changed: engine() re-loads, the images are stale
+        with torch.no_grad():
+            net.init_conv[0].conv.bias.add_(1.0)                       # parameters changed: engine() re-loads, the images are stale
         eng2 = net.engine()
         assert eng2 is eng
         assert call() == -22

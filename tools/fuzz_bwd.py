@@ -64,7 +64,7 @@ for i in range(cases):
     N.check(e.lib.ap_resblock_fwd_gate(e.ctx, layer, N.ptr(h), N.ptr(pt), N.ptr(ho2), g2.data_ptr(), B, L, N.stream()))
     if not (torch.equal(ho1, ho2) and torch.equal(g1.view(torch.int16), g2.view(torch.int16))): print("SAVE FORWARD DIFFERS", tag); bad += 1
     yb, dy, ny = guarded((B, L, 512), torch.bfloat16); db, dh, nd = guarded((B, 256, L))
-    N.check(e.lib.ap_resblock_bwd_bf16_saved(e.ctx, layer, fac.data_ptr(), N.ptr(gh), N.ptr(gs), dy.data_ptr(), N.ptr(dh), B, L, N.stream()))
+    N.check(e.lib.ap_resblock_bwd_bf16_saved(e.ctx, layer, fac.data_ptr(), N.ptr(gh), N.ptr(gs), 0, dy.data_ptr(), N.ptr(dh), B, L, N.stream()))
     if not (intact(yb, ny) and intact(db, nd)): print("OUT-OF-BOUNDS WRITE bf16 saved", tag); bad += 1
     es = float((dh - res["bf16"]).abs().max() / res["bf16"].abs().max())
     if not es < 1e-2: print("SAVED-FACTOR FORM FAR FROM THE RECOMPUTING ONE", es, tag); bad += 1
