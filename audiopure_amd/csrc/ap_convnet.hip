@@ -932,6 +932,11 @@ extern "C" int ap_debug_conv_w3(int on, int min_pairs) {
   g_conv_w3_min_pairs = min_pairs;
   return 0;
 }
+static int g_conv_p1 = 0;                     // ap_debug_conv_p1(1): the LDS-free pointwise kernel of tools/csrc/ap_conv_p1.hip for the layers it serves (A/B: measured slower)
+extern "C" int ap_debug_conv_p1(int on) {
+  g_conv_p1 = on;
+  return 0;
+}
 static long long g_conv_splitk_t2 = 384;      // ap_debug_conv_splitk: split-K is taken below this many half-tiles (2 x 128 x 128 tiles)
 static int g_conv_splitk_cap = 768;           // ... and slices are doubled while tiles x slices stays below this
 extern "C" int ap_debug_conv_splitk(int t2, int cap) {
@@ -955,6 +960,16 @@ static constexpr int g_conv_splitk_cap = 768;
 static constexpr int g_conv_w3 = 1;
 static constexpr long long g_conv_w3_min_pairs = 0;
 static constexpr int g_conv_w3_split = 1;
+#endif
+
+#ifdef AP_TOOLS
+// tools/csrc/ap_conv_p1.hip (tools library only): pointwise layers of the high-resolution maps as an LDS-free streaming GEMM on the
+// family's A-fragment image -- round 6's attempt at VERDICT r5 item 5a, measured slower than the 128 x 64 tiles (profiles/r6_conv_pointwise_streaming_ab.txt)
+namespace ap {
+bool conv_p1_serves(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int groups);
+int launch_conv_p1(const float *x, const float *afrag, const float *bias, const float *res, float *out, int B, int Cin, int H, int W, int Cout,
+                   int relu, int x_cstride, int x_coff, int o_cstride, int o_coff, size_t abytes, hipStream_t st);   // 1: not served (tensor too large)
+}
 #endif
 
 // ap_conv_w3.hip: 3 x 3 / stride 1 / pad 1 / ungrouped layers in F(2,3) form along W; their transformed-weight image is the LAST image
@@ -1228,6 +1243,16 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     const size_t abytes = conv_frag_elems(Cout, Cin / groups, kh, kw, groups) * sizeof(float);
     const bool buf = xbytes < ((size_t)1 << 31) && abytes < ((size_t)1 << 31);
     const bool p1 = kh == 1 && kw == 1 && stride == 1 && pad == 0 && !one_d && (H * W) % 4 == 0;   // pointwise: 16-byte staging
+#ifdef AP_TOOLS
+    if (g_conv_p1 && p1 && buf && !split && !splith && conv_p1_serves(B, Cin, H, W, Cout, kh, kw, stride, pad, groups)) {
+      const int rc = launch_conv_p1(x, afrag, bias, res, out, B, Cin, H, W, Cout, relu, x_cstride, x_coff, a.o_cstride, a.o_coff, abytes,
+                                    (hipStream_t)stream);
+      if (rc != 1) {
+        *cls = 7;
+        return rc;
+      }
+    }
+#endif
     if (splith) {                                               // two fp16 parts per operand, three partial products
       const void *hfrag = afrag + conv_frag_elems(Cout, Cin / groups, kh, kw, groups) +
                           conv_split_floats(Cout, Cin / groups, kh, kw, groups);

@@ -329,13 +329,17 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_bf16_kernel(
 // DSI: dskip -- the same tensor for all 36 layers of a link -- arrives as a bf16 image [clip][sample][S] (ap_bwd_bf16_rows_image, once
 // per link) instead of fp32 rows: its staging is four 16-byte loads and stores per thread and chunk, no convert, half the bytes.
 template <bool DSI>
-__global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const float *__restrict__ dh, const void *__restrict__ dskip,
-                                                                         const void *__restrict__ fac, __bf16 *__restrict__ dy,
-                                                                         const __bf16 *__restrict__ w2t, int L, int ntiles) {
+__global__ __launch_bounds__(512, 4) void resblock_bwd_gate_fac_bf16_kernel(const float *__restrict__ dh, const void *__restrict__ dskip,
+                                                                            const void *__restrict__ fac, __bf16 *__restrict__ dy,
+                                                                            const __bf16 *__restrict__ w2t, int L, int ntiles, int ntiles128) {
+  // 64-sample tiles, two workgroups per CU (66 KB of LDS, <= 128 registers): the kernel streams -- dh', dskip, factors in, dy out -- and a
+  // lone 128-sample workgroup per CU serialised its four load round trips and its epilogue with nothing to overlap them (0.17 ms per
+  // layer at B = 10; this form: see DESIGN.md 3.6)
   constexpr int C = QC_;
-  constexpr int NT = 128;
+  constexpr int NT = 64, CT = NT / 32, RPT = 128 * NT / 512;       // columns, column tiles, staged rows per thread and chunk (16)
   constexpr int ZB = NT * ZSB2_;
-  __shared__ __attribute__((aligned(16))) __bf16 lds[NT * DSB_];   // 133 KB: the dy tile of the epilogue; the Z ring aliases its start
+  __shared__ __attribute__((aligned(16))) __bf16 lds[NT * DSB_];   // 66.5 KB: the dy tile of the epilogue; the Z ring aliases its start
+  static_assert(2 * ZB <= NT * DSB_, "ring inside the dy tile");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, hh = lane >> 5;
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
   const float *dh_b = dh + (size_t)b * C * L, *ds_b = DSI ? nullptr : static_cast<const float *>(dskip) + (size_t)b * C * L;
   const __amdgpu_buffer_rsrc_t dsirs = uni_rsrc(static_cast<const char *>(dskip) + (size_t)b * ((size_t)L * C * 2), (unsigned)L * C * 2u);   // DSI: [sample][S] bf16
   const __amdgpu_buffer_rsrc_t w2rs = uni_rsrc(reinterpret_cast<const char *>(w2t) + (size_t)wave * (4 * 8 * FRB_), 4 * 8 * FRB_);
-  const __amdgpu_buffer_rsrc_t frs = uni_rsrc(reinterpret_cast<const char *>(fac) + (size_t)b * ((size_t)ntiles * 131072u), (unsigned)ntiles * 131072u);
+  const __amdgpu_buffer_rsrc_t frs = uni_rsrc(reinterpret_cast<const char *>(fac) + (size_t)b * ((size_t)ntiles128 * 131072u), (unsigned)ntiles128 * 131072u);
   const unsigned lane16 = (unsigned)lane * 16u;
 
   auto load_a2 = [&](int step) {                                 // k-step `step` of 32
@@ -363,49 +367,51 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
   a2[0] = load_a2(0);
   a2[1] = load_a2(1);
   a2[2] = load_a2(2);
-  // operand: chunk = 128 rows of [dh'; dskip] = 8 k-steps; staging thread = (column sj, 32 rows 32 sq ..)
-  const int sj = tid & 127, sq = tid >> 7;
+  // operand: chunk = 128 rows of [dh'; dskip] = 8 k-steps; staging thread = (column sj, RPT rows RPT sq ..)
+  const int sj = tid & (NT - 1), sq = tid / NT;
   const int ts = t0 + sj;
-  const unsigned zv = ts < L ? ((unsigned)ts + (unsigned)(32 * sq) * (unsigned)L) * 4u : 0x80000000u;
-  float zr[32];
-  u32x4b zq[4];
-  const unsigned ziv = ts < L ? (unsigned)ts * (unsigned)(C * 2) + (unsigned)(64 * sq) : 0x80000000u;   // DSI: this thread's 32 channels of the sample's row
+  const unsigned zv = ts < L ? ((unsigned)ts + (unsigned)(RPT * sq) * (unsigned)L) * 4u : 0x80000000u;
+  float zr[RPT];
+  u32x4b zq[RPT / 8];
+  const unsigned ziv = ts < L ? (unsigned)ts * (unsigned)(C * 2) + (unsigned)(2 * RPT * sq) : 0x80000000u;   // DSI: this thread's RPT channels of the sample's row
   auto issue_z = [&](int kc) {                                   // chunks 0, 1: dh' rows, 2, 3: dskip rows
     if (DSI && kc >= 2) {
 #pragma unroll
-      for (int o = 0; o < 4; o++) zq[o] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(dsirs, ziv + 16u * o, (kc & 1) * 256, 0));
+      for (int o = 0; o < RPT / 8; o++) zq[o] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(dsirs, ziv + 16u * o, (kc & 1) * 256, 0));
       return;
     }
     const __amdgpu_buffer_rsrc_t rs = uni_rsrc(kc < 2 ? dh_b : ds_b, clip_bytes);
 #pragma unroll
-    for (int i = 0; i < 32; i++) zr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zv, ((kc & 1) * 128 + i) * L * 4, 0));
+    for (int i = 0; i < RPT; i++) zr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, zv, ((kc & 1) * 128 + i) * L * 4, 0));
   };
   auto store_z = [&](__bf16 *dst, int kc) {
     if (DSI && kc >= 2) {
 #pragma unroll
-      for (int o = 0; o < 4; o++) *reinterpret_cast<u32x4b *>(dst + sj * ZSB2_ + 32 * sq + 8 * o) = zq[o];
+      for (int o = 0; o < RPT / 8; o++) *reinterpret_cast<u32x4b *>(dst + sj * ZSB2_ + RPT * sq + 8 * o) = zq[o];
       return;
     }
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
+    for (int o = 0; o < RPT / 8; o++) {
       float v[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) v[i] = zr[8 * o + i];
-      *reinterpret_cast<bf16x8 *>(dst + sj * ZSB2_ + 32 * sq + 8 * o) = cvt8(v);
+      *reinterpret_cast<bf16x8 *>(dst + sj * ZSB2_ + RPT * sq + 8 * o) = cvt8(v);
     }
   };
   issue_z(0);
-  // the factors this lane wrote in the forward pass: [tile][wave][column tile][q][lane] x 16 bytes; in flight under the whole GEMM
-  u32x4b fq[4][4];
+  // the factors this lane wrote in the forward pass: [128-sample tile][wave][column tile][q][lane] x 16 bytes; in flight under the whole GEMM
+  u32x4b fq[CT][4];
 #pragma unroll
-  for (int ct = 0; ct < 4; ct++)
+  for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      fq[ct][q] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(frs, lane16, ((ti * 8 + wave) * 16 + ct * 4 + q) * 1024, 2));
+    for (int q = 0; q < 4; q++) {
+      const int gct = (t0 >> 5) + ct;                            // column tile of the clip: 128-sample tile gct >> 2, its column tile gct & 3
+      fq[ct][q] = __builtin_bit_cast(u32x4b, __builtin_amdgcn_raw_buffer_load_b128(frs, lane16, (((gct >> 2) * 8 + wave) * 16 + (gct & 3) * 4 + q) * 1024, 2));
+    }
 
-  f32x16 accg[4];
+  f32x16 accg[CT];
 #pragma unroll
-  for (int ct = 0; ct < 4; ct++)
+  for (int ct = 0; ct < CT; ct++)
 #pragma unroll
     for (int r = 0; r < 16; r++) accg[ct][r] = 0.f;
   store_z(lds, 0);
@@ -418,11 +424,11 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
     for (int ks = 0; ks < 8; ks++) {
       const int nx = kc * 8 + ks + 3;
       a2[(ks + 3) & 3] = load_a2(nx < 32 ? nx : 31);
-      bf16x8 bq[4];
+      bf16x8 bq[CT];
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(zb + 32 * ct * ZSB2_ + 16 * ks);
+      for (int ct = 0; ct < CT; ct++) bq[ct] = *reinterpret_cast<const bf16x8 *>(zb + 32 * ct * ZSB2_ + 16 * ks);
 #pragma unroll
-      for (int ct = 0; ct < 4; ct++) accg[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 3], bq[ct], accg[ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ct++) accg[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks & 3], bq[ct], accg[ct], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (kc + 1 < 4) store_z(lds + ((kc + 1) & 1) * ZB, kc + 1);
@@ -432,7 +438,7 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
   // ---- epilogue: dy = factor . dg into the tile image [column][2C] (bf16), then out as whole 1 KB sample rows
   typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-  for (int ct = 0; ct < 4; ct++)
+  for (int ct = 0; ct < CT; ct++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int c0 = 32 * wave + 8 * q + 4 * hh;
@@ -452,12 +458,13 @@ __global__ __launch_bounds__(512) void resblock_bwd_gate_fac_bf16_kernel(const f
   __syncthreads();
   {
     const __amdgpu_buffer_rsrc_t ors = uni_rsrc(dy + (size_t)b * L * 2 * C, (unsigned)L * 2u * C * 2u);
-    const int col = tid >> 2, part = tid & 3;                      // a column's 1 KB row leaves as 4 x 256 B
+    constexpr int PARTS = 512 / NT, PB = 1024 / PARTS;           // a column's 1 KB row leaves as PARTS x PB bytes
+    const int col = tid / PARTS, part = tid % PARTS;
     const int t = t0 + col;
-    const unsigned off = t < L ? (unsigned)t * 1024u + (unsigned)part * 256u : 0x80000000u;
+    const unsigned off = t < L ? (unsigned)t * 1024u + (unsigned)(part * PB) : 0x80000000u;
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4b *>(lds + col * DSB_ + 128 * part + 8 * i), ors, off + 16u * i, 0, 0);
+    for (int i = 0; i < PB / 16; i++)
+      __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4b *>(lds + col * DSB_ + (PB / 2) * part + 8 * i), ors, off + 16u * i, 0, 0);
   }
 }
 
@@ -657,9 +664,9 @@ int launch_resblock_bwd_bf16_saved(ap_ctx *ctx, int layer, const void *fac, cons
   const int nt = (L + 63) / 64, nt4 = (L + 127) / 128;
   if (dskip_is_image) {
     if ((size_t)L * QC_ * 2 >= ((size_t)1 << 31)) { set_error("ap_resblock_bwd_bf16_saved: clip too long for the bf16 dskip image"); return -22; }
-    resblock_bwd_gate_fac_bf16_kernel<true><<<(unsigned)(B * nt4), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt4);
+    resblock_bwd_gate_fac_bf16_kernel<true><<<(unsigned)(B * nt), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt, nt4);
   } else {
-    resblock_bwd_gate_fac_bf16_kernel<false><<<(unsigned)(B * nt4), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt4);
+    resblock_bwd_gate_fac_bf16_kernel<false><<<(unsigned)(B * nt), 512, 0, st>>>(dhp, dskip, fac, (__bf16 *)dy, p, L, nt, nt4);
   }
   resblock_bwd_conv_bf16_kernel<<<(unsigned)(B * nt), 256, 0, st>>>((const __bf16 *)dy, dhp, dhin, p + BW_W2T_, L, d, nt);
   AP_HIP(hipGetLastError());

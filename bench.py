@@ -432,10 +432,11 @@ def bench_config4(dev, steps, B=256, n=5):
     import ctypes as C
     from audiopure_amd import _native as N
     lib = N.lib()
-    NC = 7
+    NC = 8
     names = ["conv2d_f32_big2_kernel<128,128>", "conv2d_f32_big2_kernel<64,128>", "conv2d_f32_big2_kernel<128,64>",
              "conv2d_split_kernel (split operands)", "conv2d_f32_big_kernel", "conv2d_f32_kernel (generic)",
-             "conv2d_w3_kernel (3x3 in F(2,3) form along W: executes 2/3 of the direct form's flops)"]
+             "conv2d_w3_kernel (3x3 in F(2,3) form along W: executes 2/3 of the direct form's flops)",
+             "conv1x1_stream_kernel (tools builds only)"]
     N.check(lib.ap_conv_profile_enable(1))
     with torch.no_grad():
         system(x, True)

@@ -255,3 +255,4 @@ def test_conv3x3_minimal_filtering_kernel_matches_conv2d(dev):
         N.check(lib.ap_conv2d_fwd_slice(N.ptr(x), N.ptr(wT), N.ptr(b), N.ptr(r), N.ptr(wide), B, Cin, H, W, Cout, 3, 3, 1, 1, 1, relu, Cin + 5, 3,
                                         Cout + 7, 2, N.stream()))
         assert torch.equal(wide[:, 2:2 + Cout], out) and bool((wide[:, :2] == 4.0).all()) and bool((wide[:, 2 + Cout:] == 4.0).all())
+

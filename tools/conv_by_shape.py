@@ -25,7 +25,7 @@ with torch.no_grad():
     N.check(lib.ap_conv_profile_enable(1))
     system(x, True)
     torch.cuda.synchronize()
-NAMES = ["big2<128,128>", "big2<64,128>", "big2<128,64>", "split", "big", "generic", "w3 (F(2,3))"]
+NAMES = ["big2<128,128>", "big2<64,128>", "big2<128,64>", "split", "big", "generic", "w3 (F(2,3))", "p1 (stream)"]
 agg = {}
 i = 0
 ms, fl, sh = C.c_double(), C.c_double(), (C.c_int * 10)()
