@@ -730,6 +730,12 @@ def main():
                         "accumulate and storage, 1 s @ 16 kHz clips",
             "value": round(B * st / e3, 3), "unit": "utterances/s", "steps": st, "warmup": 1,
             "ms_per_step": round(e3 * 1e3 / st, 3), "dtype": "bf16", "roofline": roofline("bf16", k3, l3), "power": run_mode.power}
+        # the same workload with the residual stream stored as bf16 (AP_PREC_BF16_STORE: SURVEY 8d's third precision row) -- its own
+        # arithmetic (one more rounding per layer), reported beside configs[3], not in place of it
+        e3s, k3s, l3s = run_mode("bf16s", 1, 1, sampler="sde", n=10)
+        other_configs["configs[3]"]["bf16_storage"] = {
+            "value": round(B / e3s, 3), "unit": "utterances/s", "steps": 1, "warmup": 1, "ms_per_step": round(e3s * 1e3, 3), "dtype": "bf16",
+            "arithmetic": PREC_NAME["bf16s"], "roofline": roofline("bf16s", k3s, l3s), "power": run_mode.power}
         net.set_precision(args.precision)
         other_configs["configs[4]"] = bench_config4(dev, max(1, min(args.steps, 5)))
 

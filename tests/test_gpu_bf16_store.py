@@ -310,3 +310,30 @@ def test_bf16_store_chain_is_hip_graph_capturable(dh, dev):
     for xin in (x, x * 0.5, x):
         assert torch.equal(dw(xin), eager(xin))
     assert len(dw._graphs) == 1 and not eager._graphs
+
+
+def test_bf16_store_sde_chain_n10_matches_its_oracle(dh, dev):
+    """BASELINE configs[3]'s sampler (RevDiffWave: VP-SDE Euler chain, diffwave_sde.py:73-134,167-212, n = 10) in AP_PREC_BF16_STORE at
+    B = 2 against the chain oracle with the same roundings (5e-3 of max) and against the fp32 oracle chain (what bf16 operands + bf16
+    storage cost over ten steps: asserted <= 3e-3; `bf16` is held to 2e-3 in tests/test_gpu_dropin.py)."""
+    import types
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    O = _oracle()
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    net, sd = _net(cfg, dev)
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=10)
+    args = types.SimpleNamespace(t=10, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1,
+                                 ddpm_path=None, ddpm_config=None)
+    rev = RevDiffWave.from_model(dw, args)
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234))
+    z = [torch.from_numpy(synth.noise(d, 2, 16000, seed=1234)) for d in range(11)]
+    dw.set_noise_source(list(z))
+    got = rev(x0.to(dev)).cpu().numpy()
+    w = O.fold_state_dict(sd)
+    ref_q = O.sde_purify(w, cfg, O.sde_tables(), x0, 10, z, bf16_store=True)
+    ref = O.sde_purify(w, cfg, O.sde_tables(), x0, 10, z)
+    err_q, err_f = rel_err(got, ref_q.numpy()), rel_err(got, ref.numpy())
+    print(f"bf16s SDE n=10: vs bf16-store oracle {err_q:.2e}, vs fp32 oracle {err_f:.2e}")
+    assert err_q < 5e-3
+    assert err_f < 3e-3
