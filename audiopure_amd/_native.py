@@ -64,6 +64,7 @@ SIGNATURES = {
     "ap_ctx_prepare_backward": (_i, [_vp, _vp]),
     "ap_init_conv_u": (_i, [_vp, _fp, _fp, _vp, _i, _i, _vp]),
     "ap_resblock_fwd_u": (_i, [_vp, _i, _vp, _fp, _vp, _vp, _i, _i, _vp]),
+    "ap_resblock_fwd_u_save": (_i, [_vp, _i, _vp, _fp, _vp, _vp, _vp, _i, _i, _vp]),
     "ap_resblock_bwd_bf16": (_i, [_vp, _i, _fp, _fp, _fp, _fp, _vp, _fp, _i, _i, _vp]),
     "ap_resblock_bwd_bf16_available": (_i, [_vp, _i, _i]),
     "ap_gate_factor_bytes": (_sz, [_i, _i]),

@@ -343,8 +343,8 @@ extern "C" int ap_ctx_prepare_backward(ap_ctx *ctx, void *stream) {
   if (ctx->bwd_ready) return 0;
   if (ctx->C != 256 || ctx->S != 256) { set_error("ap_ctx_prepare_backward: the fused backward kernels are built for res = skip = 256 channels"); return -22; }
   if (ctx->cfg.precision == AP_PREC_F32) return prepare_bwd_f32(ctx, (hipStream_t)stream);
-  if (ctx->cfg.precision == AP_PREC_BF16) return prepare_bwd_bf16(ctx, (hipStream_t)stream);
-  set_error("ap_ctx_prepare_backward: no fused backward in precision %d (AP_PREC_F32, AP_PREC_BF16)", ctx->cfg.precision);
+  if (ctx->cfg.precision == AP_PREC_BF16 || ctx->cfg.precision == AP_PREC_BF16_STORE) return prepare_bwd_bf16(ctx, (hipStream_t)stream);
+  set_error("ap_ctx_prepare_backward: no fused backward in precision %d (AP_PREC_F32, AP_PREC_BF16, AP_PREC_BF16_STORE)", ctx->cfg.precision);
   return -22;
 }
 
@@ -430,7 +430,8 @@ int check_run(ap_ctx *ctx, int B, int L, void *ws, size_t ws_bytes, const char *
 
 // the 36-layer sweep: h ping-pongs between ha/hb, skip accumulates (WaveNet.py:120-135,164-170)
 // one AP_PREC_BF16_STORE block launch (its own pair of profile events: kind 0)
-int launch_resblock_u_timed(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st) {
+int launch_resblock_u_timed(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st,
+                            void *fout = nullptr) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (ctx->profile) {
     if (ctx->ev_used + 2 > ctx->ev.size())
@@ -446,7 +447,7 @@ int launch_resblock_u_timed(ap_ctx *ctx, int layer, const void *uin, const float
     ctx->ev_used += 2;
     AP_HIP(hipEventRecord(e0, st));
   }
-  const int rc = launch_resblock_bf16u(ctx, layer, uin, pt_next, uout, gout, B, L, st);
+  const int rc = launch_resblock_bf16u(ctx, layer, uin, pt_next, uout, gout, B, L, st, fout);
   if (e1) AP_HIP(hipEventRecord(e1, st));
   return rc;
 }
@@ -594,6 +595,15 @@ extern "C" int ap_resblock_fwd_gate(ap_ctx *ctx, int layer, const float *h_in, c
   if (h_in == h_out) { set_error("ap_resblock_fwd_gate: h_out must not alias h_in"); return -22; }
   if (ctx->cfg.precision != AP_PREC_BF16) { set_error("ap_resblock_fwd_gate: AP_PREC_BF16 only"); return -22; }
   return launch_resblock(ctx, layer, h_in, part_t_layer, h_out, nullptr, 0, B, L, (hipStream_t)stream, nullptr, nullptr, g_image);
+}
+
+extern "C" int ap_resblock_fwd_u_save(ap_ctx *ctx, int layer, const void *u_in, const float *part_t_next, void *u_out, void *g_image,
+                                      void *gate_factors, int B, int L, void *stream) {
+  if (!ctx || !ctx->loaded || !u_in || !g_image || !gate_factors) { set_error("ap_resblock_fwd_u_save: not loaded / null"); return -22; }
+  if (layer < 0 || layer >= ctx->NL || B < 1 || L < 1) { set_error("ap_resblock_fwd_u_save: layer=%d B=%d L=%d", layer, B, L); return -22; }
+  if (u_out && !part_t_next) { set_error("ap_resblock_fwd_u_save: u_out needs the next layer's part_t"); return -22; }
+  if (u_in == u_out) { set_error("ap_resblock_fwd_u_save: u_out must not alias u_in"); return -22; }
+  return launch_resblock_u_timed(ctx, layer, u_in, part_t_next, u_out, g_image, B, L, (hipStream_t)stream, gate_factors);
 }
 
 extern "C" size_t ap_gate_factor_bytes(int B, int L) {

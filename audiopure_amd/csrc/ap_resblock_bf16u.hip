@@ -57,6 +57,28 @@ __device__ __forceinline__ f32x2 gate_pair_u(f32x2 a, f32x2 b) {
   return (1.0f - E) * r;
 }
 
+// the same gate, also handing out its two derivative factors sg (1 - th^2), th sg (1 - sg) (ap_resblock_bf16p.hip: gate_fast2_save; the
+// returned gate is gate_pair_u's, operation for operation)
+__device__ __forceinline__ f32x2 gate_pair_u_save(f32x2 a, f32x2 b, f32x2 &f1, f32x2 &f2) {
+#pragma clang fp contract(off)
+  const f32x2 ac = {__builtin_amdgcn_fmed3f(a[0], -16.0f, 16.0f), __builtin_amdgcn_fmed3f(a[1], -16.0f, 16.0f)};
+  const f32x2 ea = ac * -2.885390081777926815f;
+  const f32x2 eb = b * -1.442695040888963407f;
+  const f32x2 E = {__builtin_amdgcn_exp2f(ea[0]), __builtin_amdgcn_exp2f(ea[1])};
+  const f32x2 F = {__builtin_amdgcn_exp2f(eb[0]), __builtin_amdgcn_exp2f(eb[1])};
+  const f32x2 opE = E + 1.0f, opF = F + 1.0f;
+  const f32x2 den = opE * opF;
+  const f32x2 r = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  const f32x2 g = (1.0f - E) * r;
+  const f32x2 sg = opE * r;
+  f32x2 th = g * opF;
+  th[0] = F[0] > 3.0e38f ? 0.f : th[0];
+  th[1] = F[1] > 3.0e38f ? 0.f : th[1];
+  f1 = sg * (1.0f - th * th);
+  f2 = g * (1.0f - sg);
+  return g;
+}
+
 using I0 = std::integral_constant<int, 0>;
 using I1 = std::integral_constant<int, 1>;
 using I2 = std::integral_constant<int, 2>;
@@ -101,12 +123,16 @@ int launch_init_conv_u(ap_ctx *ctx, const float *x, const float *pt0, void *u, i
 // NCHR (tools builds instantiate values below 8; timing only, results wrong by construction): GEMM1 runs the first NCHR of its 8
 // chunks -- what the launch would cost with that share of the dilated conv's matrix work gone and NOTHING added for it, i.e. an
 // upper bound on what a minimal-filtering form of GEMM1 (2/3 of the products) could gain (tools/ab_bf16u_flops.py).
-template <bool NOH, int NCHR = 8>
+// SAVEF (the differentiable purifier's forward pass, ap_resblock_fwd_u_save): + the gate's derivative factors, an fp16 pair per (channel,
+// sample) in the accumulators' order [clip][tile][wave][column tile][q][lane] x 16 bytes -- the image ap_resblock_bwd_bf16_saved reads
+// (ap_resblock_bf16p.hip, SAVEF: same geometry); u' and the g image are bit-identical to the launch without it.
+template <bool NOH, int NCHR = 8, bool SAVEF = false>
 __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
     const void *__restrict__ uin, void *__restrict__ uout, const float *__restrict__ ptn,       // images in / out, the NEXT layer's part_t
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
     const void *__restrict__ bbase, unsigned bbytes, unsigned b1_off, unsigned b2_off,        // fp32 bias vectors (one slab)
-    int L, int d, int ntiles, int nblk, void *__restrict__ gout) {                            // this layer's g image [clip][L][256] bf16
+    int L, int d, int ntiles, int nblk, void *__restrict__ gout,                              // this layer's g image [clip][L][256] bf16
+    void *__restrict__ fout = nullptr) {                                                      // SAVEF: the gate's derivative factors
   constexpr int C = 256, NW = 8, NCH = C / KC_, NKS = C / 16;
   constexpr int XS = XS_;
   constexpr int XBYTES = PT_ * XS * 2;                         // 26,624 B per X buffer, two buffers
@@ -365,13 +391,32 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
 #pragma unroll
       for (int qq = 0; qq < 4; qq++) {
         unsigned pk[2];
+        u32x4 fq;
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
           const f32x2 a2 = {acc[0][ct][4 * qq + e], acc[0][ct][4 * qq + e + 1]};
           const f32x2 b2 = {acc[1][ct][4 * qq + e], acc[1][ct][4 * qq + e + 1]};
-          pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(gate_pair_u(a2, b2), bf16x2));
+          f32x2 g2;
+          if constexpr (SAVEF) {
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            f32x2 f1, f2;
+            g2 = gate_pair_u_save(a2, b2, f1, f2);
+            fq[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{f1[0], f2[0]}, f16x2));       // (tanh factor, sigmoid factor) of element e
+            fq[e + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{f1[1], f2[1]}, f16x2));
+          } else {
+            g2 = gate_pair_u(a2, b2);
+          }
+          pk[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(g2, bf16x2));
         }
         *reinterpret_cast<uint2 *>(lds + GOFF + ((32 * ct + j) * GS_ + 32 * wave + 8 * qq + 4 * hh) * 2) = make_uint2(pk[0], pk[1]);
+        if constexpr (SAVEF) {
+          const uint64_t fb = (uint64_t)fout + (uint64_t)b_cur * ((uint64_t)ntiles * 131072u);
+          const uint32_t flo = __builtin_amdgcn_readfirstlane((uint32_t)fb), fhi = __builtin_amdgcn_readfirstlane((uint32_t)(fb >> 32));
+          const __amdgpu_buffer_rsrc_t frs =
+              __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)fhi << 32) | flo), 0, (int)((unsigned)ntiles * 131072u), 0x00020000);
+          // (the whole offset in the VGPR, soffset = 0: see the note on 16-byte buffer stores in ap_resblock_bf16p.hip)
+          __builtin_amdgcn_raw_buffer_store_b128(fq, frs, (unsigned)ln * 16u + (unsigned)((((t0 / PT_) * 8 + wave) * 16 + ct * 4 + qq) * 1024), 0, 2);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -515,7 +560,8 @@ bool resblock_bf16u_serves(const ap_ctx *ctx, int L) {
 }
 
 // uout null: the net's last layer (no res_conv, no image out)
-int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st) {
+int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st,
+                          void *fout) {
   if (!resblock_bf16u_serves(ctx, L)) {
     set_error("AP_PREC_BF16_STORE: built for res = skip = 256 channels, clips shorter than 2^22 samples (got %d / %d, L = %d)", ctx->C, ctx->S, L);
     return -22;
@@ -549,6 +595,17 @@ int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *
     return 0;
   }
 #endif
+  if (fout) {                                                    // the differentiable purifier's forward: + the gate's derivative factors
+    if ((size_t)ntiles * 131072 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16_STORE: clip too long for the gate-factor image"); return -22; }
+    if (uout)
+      resblock_bf16u_kernel<false, 8, true><<<(unsigned)grid, 512, 0, st>>>(uin, uout, pt_next, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off,
+                                                                            L, d, ntiles, nblk, gout, fout);
+    else
+      resblock_bf16u_kernel<true, 8, true><<<(unsigned)grid, 512, 0, st>>>(uin, nullptr, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off,
+                                                                           L, d, ntiles, nblk, gout, fout);
+    AP_HIP(hipGetLastError());
+    return 0;
+  }
   if (uout)
     resblock_bf16u_kernel<false><<<(unsigned)grid, 512, 0, st>>>(uin, uout, pt_next, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d,
                                                                  ntiles, nblk, gout);

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void resblock_bwd_conv_bf16_kernel(const __
 }
 
 bool resblock_bwd_bf16_serves(const ap_ctx *ctx, int B, int L) {
-  if (ctx->cfg.precision != AP_PREC_BF16 || ctx->C != QC_ || ctx->S != QC_ || !ctx->loaded) return false;
+  if ((ctx->cfg.precision != AP_PREC_BF16 && ctx->cfg.precision != AP_PREC_BF16_STORE) || ctx->C != QC_ || ctx->S != QC_ || !ctx->loaded) return false;
   if ((size_t)2 * QC_ * (size_t)L * 4 >= ((size_t)1 << 31)) return false;
   return (long long)B * ((L + 63) / 64) < (1ll << 31);
 }

@@ -201,8 +201,8 @@ class WaveNet_Speech_Commands(nn.Module):
         bf16 parts, six partial products per product on the bf16 MFMA, fp32 accumulate -- fp32-class results (held to the fp32
         tolerances and, on adversarial operands, to twice the direct fp32 kernel's error against fp64), ~1.3x the F(2,3) form's rate.
         "bf16": bf16 MFMA operands, fp32 accumulate and storage (BASELINE configs[3]).  "bf16s": the same arithmetic with the
-        residual stream stored as bf16 between layers (SURVEY.md 8d "bf16 MFMA, bf16 storage"; one more rounding per layer,
-        forward only).  All but "f32" need res_channels = 256."""
+        residual stream stored as bf16 between layers (SURVEY.md 8d "bf16 MFMA, bf16 storage"; one more rounding per layer;
+        input gradients through the bf16 backward kernels).  All but "f32" need res_channels = 256."""
         modes = {"f32": N.AP_PREC_F32, "fp32": N.AP_PREC_F32, "f32d": N.AP_PREC_F32, "bf16": N.AP_PREC_BF16,
                  "f32s": N.AP_PREC_F32_SPLIT, "f32_split": N.AP_PREC_F32_SPLIT, "f32sw": N.AP_PREC_F32_SPLIT, "bf16s": N.AP_PREC_BF16_STORE,
                  "bf16_store": N.AP_PREC_BF16_STORE}

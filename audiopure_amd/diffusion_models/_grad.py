@@ -15,7 +15,8 @@ chain fits a memory budget (``SAVE_BUDGET_BYTES``; 288 GB of HBM hold a PGD batc
 activations (``ap_resblock_fwd_save``) and a block's backward is ``ap_resblock_bwd`` -- two fused launches (the gate's
 derivative behind ``W2^T [dh'; dskip]``, then the transposed dilated conv in F(2,3) form with the residual path in its
 epilogue): the forward block's flops, no elementwise glue.  bf16 mode at the same shape: ``ap_resblock_bwd_bf16`` -- two launches per
-layer on the bf16 matrix pipe from the layer inputs (the dilated conv recomputed inside).  Every other shape / arithmetic mode: the residual blocks'
+layer on the bf16 matrix pipe from the layer inputs (the dilated conv recomputed inside), or -- the default -- ``ap_resblock_bwd_bf16_saved``
+from gate derivative factors the forward kept; bf16-storage mode: the same backward behind ``ap_resblock_fwd_u_save``.  Every other shape / arithmetic mode: the residual blocks'
 forward is the fused kernel (``ap_resblock_fwd``), the three GEMM-shaped backward terms of a block -- the recomputed dilated conv, ``W2^T [dh'; dskip]`` and the transposed
 dilated conv -- are ``ap_conv2d_fwd`` calls in ``AP_CONV_1D`` mode (MFMA conv-as-GEMM, weights streamed as
 fragments), with ``ap_gate_bwd`` / ``ap_relu_outer_bwd`` / ``ap_init_conv_bwd`` between them.  Gradients with respect
@@ -54,10 +55,9 @@ class EpsGrad:
         lib, dev = eng.lib, next(net.parameters()).device
         C_, S_, NL = eng.cfg.res_channels, eng.cfg.skip_channels, eng.cfg.num_res_layers
         cyc = eng.cfg.dilation_cycle
-        if net._precision == N.AP_PREC_BF16_STORE:
-            raise N.NativeError("set_precision('bf16s') (AP_PREC_BF16_STORE) is forward-only: no backward is built for the bf16 residual "
-                                "stream; use 'bf16' or 'f32' for the differentiable purifier")
-        if C_ == 256 and S_ == 256 and net._precision in (N.AP_PREC_F32, N.AP_PREC_BF16):
+        if net._precision == N.AP_PREC_BF16_STORE and not (C_ == 256 and S_ == 256):
+            raise N.NativeError("set_precision('bf16s') (AP_PREC_BF16_STORE) needs res = skip = 256 channels")
+        if C_ == 256 and S_ == 256 and net._precision in (N.AP_PREC_F32, N.AP_PREC_BF16, N.AP_PREC_BF16_STORE):
             # the fused backward kernels' own weight images: built here, once per load, outside any stream capture (the launch
             # functions allocate nothing: include/audiopure.h, ap_ctx_prepare_backward)
             N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()), "ap_ctx_prepare_backward")
@@ -99,7 +99,7 @@ class EpsGrad:
         return eng
 
     def _conv(self, lib, x, packed, bias, res, out, B, Cin, L, Cout, kw, pad, dil, flags=0):
-        if self.net._precision in (N.AP_PREC_F32_SPLIT, N.AP_PREC_BF16):   # follow the network's arithmetic mode: the split GEMM (fp32-class
+        if self.net._precision in (N.AP_PREC_F32_SPLIT, N.AP_PREC_BF16, N.AP_PREC_BF16_STORE):   # follow the network's arithmetic mode: the split GEMM (fp32-class
             flags |= 0x100                                       # results from the bf16 matrix pipe, AP_CONV_SPLIT) where the forward ran on that pipe too
         fl = flags | _F1D | ((dil << 16) if dil > 1 else 0)
         N.use_conv_workspace(x.device)                           # short clips meet the split-K condition: this device's buffer
@@ -114,8 +114,10 @@ class EpsGrad:
         eng = self._prepare()
         B, _, L = x.shape
         C_, S_, NL = self.C, self.S, self.NL
-        keeps = acts and self._keeps_factors(eng, B, L)
-        n = (3 if keeps else NL + 1) * B * C_ * L + B * S_ * L + NL * C_ + eng.cfg.embed_dim_out   # (kept factors: layer 0's input + a ping-pong pair)
+        bstore = self.net._precision == N.AP_PREC_BF16_STORE
+        keeps = bstore or (acts and self._keeps_factors(eng, B, L))
+        # (kept factors: layer 0's input + a ping-pong pair -- a pair of bf16 u images, half the bytes, with bf16 storage)
+        n = ((2 if bstore else 3) if keeps else NL + 1) * B * C_ * L + B * S_ * L + NL * C_ + eng.cfg.embed_dim_out
         if acts and self.net._precision == N.AP_PREC_F32 and C_ in (64, 256):
             n += NL * B * 2 * C_ * L
         extra = 0
@@ -136,7 +138,8 @@ class EpsGrad:
 
     def _group(self, eng) -> int:
         """Layers per skip GEMM of forward_save's deferred-skip form (bf16 mode; 0: the fused block per layer)."""
-        return int(eng.skip_group or 0) if getattr(eng, "_ds_ok", False) and self.net._precision == N.AP_PREC_BF16 else 0
+        return (int(eng.skip_group or 0) if getattr(eng, "_ds_ok", False) and
+                self.net._precision in (N.AP_PREC_BF16, N.AP_PREC_BF16_STORE) else 0)
 
     def eps_only(self, x: torch.Tensor, step: float):
         """The plain fused forward (``ap_eps_fwd``): what the chain's forward pass calls -- nothing is kept."""
@@ -154,6 +157,8 @@ class EpsGrad:
         C_, S_, NL = self.C, self.S, self.NL
         part = torch.empty(NL * C_ + eng.cfg.embed_dim_out, device=dev)
         N.check(lib.ap_embed(eng.ctx, float(step), N.ptr(part), N.stream()), "ap_embed")
+        if self.net._precision == N.AP_PREC_BF16_STORE:
+            return self._forward_save_bstore(eng, x, step, part)
         keeps = acts and self._keeps_factors(eng, B, L)
         # with kept gate factors the backward needs no layer input but the first (ap_init_conv_bwd): hs = [h_0, ping, pong]
         hs = torch.empty((3 if keeps else NL + 1, B, C_, L), device=dev)
@@ -199,6 +204,42 @@ class EpsGrad:
         N.check(lib.ap_final_affine(eng.ctx, N.ptr(skip), None, N.ptr(eps), None, 0.0, 0.0, 0.0, None, 0, 0, 0, B, L,
                                     N.stream()), "ap_final_affine")
         return eps, (hs, skip, part, pre)
+
+    def _forward_save_bstore(self, eng, x, step, part):
+        """AP_PREC_BF16_STORE: the sweep ap_eps_fwd runs in this mode (ap_init_conv_u, ap_resblock_fwd_u per layer, one ap_skip_gemm per
+        group: eps equals ap_eps_fwd's bit for bit) with every block also keeping its gate's derivative factors
+        (ap_resblock_fwd_u_save).  The backward is the bf16 mode's (ap_resblock_bwd_bf16_saved): the rounding of the stored residual
+        passes the gradient straight through, everything else about the two forwards is the same arithmetic.  There is no lean
+        form (no fp32 layer inputs exist to recompute from): a link either keeps its factors or is recomputed whole."""
+        lib, dev = eng.lib, x.device
+        B, _, L = x.shape
+        C_, S_, NL = self.C, self.S, self.NL
+        G = self._group(eng)
+        if G <= 0 or not lib.ap_resblock_bwd_bf16_available(eng.ctx, B, L):
+            raise N.NativeError("set_precision('bf16s'): no backward for this shape (res = skip = 256 channels, the deferred-skip form)")
+        hs = torch.empty((1, B, C_, L), device=dev)                         # h_0 in fp32: what ap_init_conv_bwd reads
+        N.check(lib.ap_init_conv(eng.ctx, N.ptr(x), N.ptr(hs[0]), B, L, N.stream()), "ap_init_conv")
+        u = torch.empty((2, B * C_ * L), device=dev, dtype=torch.bfloat16)  # the residual stream's ping-pong pair of u images
+        N.check(lib.ap_init_conv_u(eng.ctx, N.ptr(x), N.ptr(part[:C_]), u[0].data_ptr(), B, L, N.stream()), "ap_init_conv_u")
+        skip = torch.empty((B, S_, L), device=dev)
+        need = min(G, NL) * B * L * C_
+        if self._gimg is None or self._gimg.numel() < need or self._gimg.device != dev:
+            self._gimg = None
+            self._gimg = torch.empty(need, device=dev, dtype=torch.bfloat16)
+        gimg = self._gimg[:need].view(min(G, NL), B, L, C_)
+        fac = torch.empty((NL, int(lib.ap_gate_factor_bytes(B, L))), device=dev, dtype=torch.uint8)
+        for n0 in range(0, NL, G):
+            nl = min(G, NL - n0)
+            for n in range(n0, n0 + nl):
+                last = n + 1 == NL
+                N.check(lib.ap_resblock_fwd_u_save(eng.ctx, n, u[n & 1].data_ptr(), None if last else N.ptr(part[(n + 1) * C_:(n + 2) * C_]),
+                                                   None if last else u[(n + 1) & 1].data_ptr(), gimg[n - n0].data_ptr(), fac[n].data_ptr(),
+                                                   B, L, N.stream()), "ap_resblock_fwd_u_save")
+            N.check(lib.ap_skip_gemm(eng.ctx, n0, nl, gimg.data_ptr(), N.ptr(skip), 1 if n0 else 0, B, L, N.stream()), "ap_skip_gemm")
+        eps = torch.empty((B, 1, L), device=dev)
+        N.check(lib.ap_final_affine(eng.ctx, N.ptr(skip), None, N.ptr(eps), None, 0.0, 0.0, 0.0, None, 0, 0, 0, B, L,
+                                    N.stream()), "ap_final_affine")
+        return eps, (hs, skip, part, fac)
 
     def backward(self, saved, d_eps: torch.Tensor) -> torch.Tensor:
         """J_eps(x, t)^T d_eps for the evaluation ``saved`` came from."""

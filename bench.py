@@ -778,15 +778,15 @@ def main():
         x10 = x0_full[:min(10, B)].contiguous()
         y10 = torch.zeros(x10.shape[0], dtype=torch.long, device=dev)
         one_shot, grad_step = {}, {}
-        for prec in ("f32", "bf16"):
+        for prec in ("f32", "bf16", "bf16s"):
             net.set_precision(prec)
             dwc = DiffWave(model=net, diffusion_hyperparams=dh_, reverse_timestep=n)
             dwc.set_noise_source(("philox", 1234, 0))
             with torch.no_grad():
                 t_os = timed(lambda: m5(dwc.one_shot_denoise(x10)))
             one_shot[prec] = {"B": x10.shape[0], "ms": round(t_os * 1e3, 3), "clips_per_s": round(x10.shape[0] / t_os, 2)}
-            # both arithmetic modes: fp32 keeps the pre-gate activations and runs ap_resblock_bwd, bf16 keeps the layer inputs only and runs
-            # ap_resblock_bwd_bf16 (the dilated conv recomputed on the bf16 matrix pipe)
+            # fp32 keeps the pre-gate activations and runs ap_resblock_bwd; bf16 / bf16s keep the gate's derivative factors (an fp16 pair per
+            # element) and run ap_resblock_bwd_bf16_saved on the bf16 matrix pipe
             runner = RevDiffWave.from_model(dwc, types.SimpleNamespace(t=n, score_type="guided_diffusion", rand_t=False, t_delta=0,
                                                                          use_bm=False, sample_step=1))
             sysg = AcousticSystem(classifier=m5, transform=None, defender=runner, defense_type="wave")

@@ -61,7 +61,8 @@ enum {
                              row): each layer hands the next one u = bf16(h' + part_t of that layer) -- the dilated conv's operand
                              and, by the reference's in-place alias (WaveNet.py:77,84), the value the residual carries -- as an
                              image [B][C/32][L][32] (ap_resblock_fwd_u); skip stays fp32 (deferred-skip form).  One more rounding
-                             per layer than AP_PREC_BF16 (the residual sees bf16(u) instead of fp32 u).  Forward only.  C = 256. */
+                             per layer than AP_PREC_BF16 (the residual sees bf16(u) instead of fp32 u).  Input gradients through
+                             ap_resblock_fwd_u_save + ap_resblock_bwd_bf16_saved (the bf16 backward kernels).  C = 256. */
 };
 
 /* configs/config.json "wavenet_config" + "diffusion_config" (reference: configs/config.json:2-17) */
@@ -205,10 +206,16 @@ int ap_ctx_set_skip_group(ap_ctx *ctx, int layers_per_group);
  *   ap_resblock_fwd_u: y = DilConv(u_in) + b;  g = tanh . sigmoid;  h' = (u_in + W_res bf16(g) + b_res) sqrt(1/2)   (WaveNet.py:87-97);
  *                      u_out = bf16(h' + part_t_next) (part_t_next: [C] of layer + 1), g_image [B][L][C] bf16 for ap_skip_gemm.
  *                      u_out NULL (the net's last layer, whose h' nobody reads: WaveNet.py:131-135): res_conv and the store are left out.
- * ap_resblock_fwd / _gate / _save return -22 in this mode (their h tensors are fp32).  ap_eps_fwd / ap_purify_* run the whole sweep. */
+ * ap_resblock_fwd / _gate / _save return -22 in this mode (their h tensors are fp32; ap_resblock_bwd_bf16 recomputes from an fp32
+ * layer input this mode never forms: use ap_resblock_fwd_u_save + ap_resblock_bwd_bf16_saved).
+ * ap_eps_fwd / ap_purify_* run the whole sweep. */
 int ap_init_conv_u(ap_ctx *ctx, const float *x, const float *part_t_layer0, void *u_out, int B, int L, void *stream);
 int ap_resblock_fwd_u(ap_ctx *ctx, int layer, const void *u_in, const float *part_t_next, void *u_out, void *g_image, int B, int L,
                       void *stream);
+/* ... and the form that also keeps the gate's derivative factors for ap_resblock_bwd_bf16_saved (see ap_resblock_fwd_gate_save): the
+ * gradient of the bf16-storage forward is the bf16 backward's with the rounding of u passed straight through. */
+int ap_resblock_fwd_u_save(ap_ctx *ctx, int layer, const void *u_in, const float *part_t_next, void *u_out, void *g_image,
+                           void *gate_factors, int B, int L, void *stream);
 
 /* AP_PREC_F32 arithmetic form of the dilated conv (WaveNet.py:87).  1 (default where built: res = skip = 256 channels): the
  * F(2,3) minimal-filtering form over the dilation pair -- outputs t and t + d share their four taps, so the pair costs four

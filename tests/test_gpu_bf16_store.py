@@ -275,20 +275,144 @@ def test_bf16_store_full_batch_equals_small_batches_bit_for_bit(dev, dh):
     assert torch.equal(dw(x[510:]), big[510:])
 
 
-def test_bf16_store_is_forward_only_and_says_so(dev, dh):
-    """No backward is built for the bf16 residual stream: asking for a gradient raises (never a silently detached result), and the
-    fp32-tensor block entry points refuse the mode."""
+def _cos(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("L,layer", [(2048, 0), (1500, 5), (16000, 10), (130, 3), (1, 0), (129, 6), (4133, 7), (128, 8), (1003, 4)])
+def test_bf16_store_block_backward_from_its_kept_gate_factors(dev, L, layer):
+    """The differentiable purifier in AP_PREC_BF16_STORE: ap_resblock_fwd_u_save = ap_resblock_fwd_u (u', g image bit
+    for bit) + the gate's derivative factors; ap_resblock_bwd_bf16_saved turns them into the block's input gradient -- against torch
+    autograd through the oracle block with bf16_store=True (the rounding of the stored u passes the gradient through): cosine >=
+    0.999, max deviation <= 2e-2 of the largest entry (AP_PREC_BF16's backward bars, tests/test_gpu_grad.py)."""
+    from audiopure_amd import _native as N
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 12, 12)
+    net, sd = _net(cfg, dev, seed=3)
+    w = O.fold_state_dict(sd)
+    eng = net.engine()
+    lib = eng.lib
+    B, C_, d = 2, 256, 2 ** (layer % 12)
+    assert lib.ap_resblock_bwd_bf16_available(eng.ctx, B, L) == 1
+    N.check(lib.ap_ctx_prepare_backward(eng.ctx, N.stream()))
+    h = torch.from_numpy(synth.uniform(f"gh/{L}", (B, C_, L), 1, -1.5, 1.5))
+    gh = torch.from_numpy(synth.uniform(f"gg/{L}", (B, C_, L), 2, -1.0, 1.0))
+    gs = torch.from_numpy(synth.uniform(f"gs/{L}", (B, C_, L), 3, -1.0, 1.0))
+    emb = torch.from_numpy(synth.uniform("emb", (1, 512), 1, -1.0, 1.0)).repeat(B, 1)
+    with torch.no_grad():
+        def part(n):
+            p = f"residual_layer.residual_blocks.{n}"
+            return torch.nn.functional.linear(emb[:1], w[p + ".fc_t.weight"], w[p + ".fc_t.bias"]).reshape(-1)
+        pt, ptn = part(layer), part(layer + 1)
+        u_in = _bf16(h + pt.view(1, -1, 1))
+    hr = h.clone().requires_grad_(True)
+    h_ref, s_ref = O.residual_block(w, layer, d, hr, emb, bf16_store=True)
+    (g_ref,) = torch.autograd.grad([h_ref, s_ref], hr, [gh, gs])
+    uin = to_uimg(u_in.to(dev))
+    uo, uo2 = torch.zeros_like(uin), torch.zeros_like(uin)
+    gi, gi2, gi3 = (torch.empty((B, L, C_), dtype=torch.bfloat16, device=dev) for _ in range(3))
+    nfac = lib.ap_gate_factor_bytes(B, L)
+    guard = 4096
+    buf = torch.full((nfac + 2 * guard,), 0xA5, dtype=torch.uint8, device=dev)
+    fac = buf[guard:guard + nfac]
+    ptn_d, ghd, gsd = ptn.to(dev), gh.to(dev), gs.to(dev)
+    N.check(lib.ap_resblock_fwd_u_save(eng.ctx, layer, uin.data_ptr(), N.ptr(ptn_d), uo.data_ptr(), gi.data_ptr(), fac.data_ptr(), B, L, N.stream()))
+    N.check(lib.ap_resblock_fwd_u(eng.ctx, layer, uin.data_ptr(), N.ptr(ptn_d), uo2.data_ptr(), gi2.data_ptr(), B, L, N.stream()))
+    assert torch.equal(uo.view(torch.int16), uo2.view(torch.int16)) and torch.equal(gi.view(torch.int16), gi2.view(torch.int16))
+    assert bool((buf[:guard] == 0xA5).all()) and bool((buf[guard + nfac:] == 0xA5).all())      # the factor image stays inside its bytes
+    fac3 = torch.zeros(nfac, dtype=torch.uint8, device=dev)       # u_out = NULL (the net's last layer): same g image, same factors
+    N.check(lib.ap_resblock_fwd_u_save(eng.ctx, layer, uin.data_ptr(), None, None, gi3.data_ptr(), fac3.data_ptr(), B, L, N.stream()))
+    assert torch.equal(gi3.view(torch.int16), gi.view(torch.int16))
+    # (rows past L of a ragged last tile hold whatever the zero-padded columns gave: compared through the backward, which masks them)
+    dy = torch.empty((B, L, 2 * C_), dtype=torch.bfloat16, device=dev)
+    dh, dh3 = torch.empty((B, C_, L), device=dev), torch.empty((B, C_, L), device=dev)
+    N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, layer, fac.data_ptr(), N.ptr(ghd), N.ptr(gsd), 0, dy.data_ptr(), N.ptr(dh), B, L, N.stream()))
+    N.check(lib.ap_resblock_bwd_bf16_saved(eng.ctx, layer, fac3.data_ptr(), N.ptr(ghd), N.ptr(gsd), 0, dy.data_ptr(), N.ptr(dh3), B, L, N.stream()))
+    got = dh.cpu()
+    assert torch.isfinite(got).all() and torch.equal(dh3.cpu(), got)
+    assert _cos(got, g_ref) >= 0.999, (_cos(got, g_ref),)
+    assert rel_err(got.numpy(), g_ref.numpy()) <= 2e-2
+    # kernel against kernel: AP_PREC_BF16's saving block fed h = u, part_t = 0 sees the same operands (K order permuted inside a chunk)
+    netb, _ = _net(cfg, dev, seed=3, mode="bf16")
+    engb = netb.engine()
+    N.check(lib.ap_ctx_prepare_backward(engb.ctx, N.stream()))
+    facb = torch.zeros(nfac, dtype=torch.uint8, device=dev)
+    hb, zero = u_in.to(dev).contiguous(), torch.zeros(C_, device=dev)
+    N.check(lib.ap_resblock_fwd_gate_save(engb.ctx, layer, N.ptr(hb), N.ptr(zero), None, gi2.data_ptr(), facb.data_ptr(), B, L, N.stream()))
+    dhb = torch.empty_like(dh)
+    N.check(lib.ap_resblock_bwd_bf16_saved(engb.ctx, layer, facb.data_ptr(), N.ptr(ghd), N.ptr(gsd), 0, dy.data_ptr(), N.ptr(dhb), B, L, N.stream()))
+    assert rel_err(got.numpy(), dhb.cpu().numpy()) <= 2e-3
+
+
+def test_bf16_store_eps_vjp_matches_the_bf16_store_oracle_and_the_bf16_mode(dev):
+    """The whole eps VJP in AP_PREC_BF16_STORE (EpsGrad: ap_resblock_fwd_u_save per layer, then the bf16 backward kernels): the
+    saving forward's eps equals ap_eps_fwd's bit for bit; the gradient against autograd through the oracle network with
+    bf16_store=True: cosine >= 0.999 and no farther from it (relative L2) than the oracle's own fp32 gradient is; against the
+    `bf16` mode's gradient on the same weights: cosine >= 0.999."""
+    from audiopure_amd.diffusion_models._grad import EpsGrad
+    O = _oracle()
+    cfg = synth.mini_wavenet_config(256, 6, 12)
+    net, sd = _net(cfg, dev, seed=6)
+    w = O.fold_state_dict(sd)
+    B, L, step = 2, 1500, 3.0
+    x = torch.from_numpy(synth.waveforms(B, L, seed=11))
+    v = torch.from_numpy(synth.uniform(f"v{L}", (B, 1, L), 1, -1.0, 1.0))
+    refs = {}
+    for name, kw in (("bf16s", dict(bf16_store=True)), ("f32", {})):
+        xr = x.clone().requires_grad_(True)
+        (refs[name],) = torch.autograd.grad(O.eps_net(w, cfg, xr, torch.full((B, 1), step), **kw), xr, v)
+    eg = EpsGrad(net)
+    xd, vd = x.to(dev), v.to(dev)
+    eps, saved = eg.forward_save(xd, step)
+    assert saved[3].dtype == torch.uint8 and saved[0].shape[0] == 1
+    assert torch.equal(eps, eg.eps_only(xd, step))
+    assert eg.saved_bytes(xd, True) == eg.saved_bytes(xd, False)  # no lean form: a link keeps its factors or is recomputed whole
+    g = eg.backward(saved, vd).cpu()
+    eps_b, saved_b = eg.forward_save(xd, step, acts=False)       # (asked for the lean form: the same full one)
+    assert torch.equal(eps_b, eps) and torch.equal(eg.backward(saved_b, vd).cpu(), g)
+    l2 = lambda a, b: float((a - b).norm() / b.norm())
+    assert _cos(g, refs["bf16s"]) >= 0.999, _cos(g, refs["bf16s"])
+    assert l2(g, refs["bf16s"]) <= l2(refs["f32"], refs["bf16s"]), (l2(g, refs["bf16s"]), l2(refs["f32"], refs["bf16s"]))
+    netb, _ = _net(cfg, dev, seed=6, mode="bf16")
+    egb = EpsGrad(netb)
+    gb = egb.backward(egb.forward_save(xd, step)[1], vd).cpu()
+    assert _cos(g, gb) >= 0.999, _cos(g, gb)
+
+
+def test_bf16_store_purifier_is_differentiable_end_to_end(dev, dh):
+    """robustness_eval/white_box_attack.py:392,437-439 back-propagates through the defender: in AP_PREC_BF16_STORE the DDPM one-shot
+    denoiser (diffwave_ddpm.py:174-182) and the Euler chain (RevDiffWave) hand back input gradients that agree with the `bf16`
+    mode's (cosine >= 0.995 through the shipped 36-layer net and a 3-link chain); eps(x) with requires_grad works the same way.  The
+    fp32-tensor block entry points still refuse the mode (there is no fp32 h in it)."""
+    import types
     from audiopure_amd import _native as N
     from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
-    cfg = synth.mini_wavenet_config(256, 12, 12)
-    net, _ = _net(cfg, dev, seed=5)
-    x = torch.from_numpy(synth.waveforms(1, 512, seed=2)).to(dev).requires_grad_(True)
-    with pytest.raises(N.NativeError, match="forward-only"):
-        net.eps(x, 1.0)
-    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=2)
-    with pytest.raises(N.NativeError, match="forward-only"):
-        dw.one_shot_denoise(x)                                   # differentiable in the reference (diffwave_ddpm.py:174-182); forward() is no_grad there too
-    assert not dw(x).requires_grad
+    from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
+    cfg = dict(synth.FULL_WAVENET_CONFIG)
+    x0 = torch.from_numpy(synth.waveforms(2, 4000, seed=2)).to(dev)
+    wgt = torch.from_numpy(synth.uniform("w", (2, 1, 4000), 5, -1.0, 1.0)).to(dev)
+    grads = {}
+    for mode in ("bf16s", "bf16"):
+        net, _ = _net(cfg, dev, seed=0, mode=mode)
+        dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=3)
+        args = types.SimpleNamespace(t=3, score_type="guided_diffusion", rand_t=False, t_delta=0, use_bm=False, sample_step=1,
+                                     ddpm_path=None, ddpm_config=None)
+        rev = RevDiffWave.from_model(dw, args)
+        out = {}
+        for name, fn in (("one_shot", dw.one_shot_denoise), ("chain", rev), ("eps", lambda t: net.eps(t, 2.0))):
+            xg = x0.clone().requires_grad_(True)
+            torch.manual_seed(3)                                  # the chains draw torch.randn on the device: the same draws in both modes
+            y = fn(xg)
+            assert y.requires_grad
+            (y * wgt.view_as(y)).sum().backward()
+            assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().max()) > 0
+            out[name] = xg.grad.cpu()
+        grads[mode] = out
+    for name in ("one_shot", "chain", "eps"):
+        c = _cos(grads["bf16s"][name], grads["bf16"][name])
+        assert c >= 0.995, (name, c)
+    net, _ = _net(synth.mini_wavenet_config(256, 12, 12), dev, seed=5)
     eng = net.engine()
     h = torch.zeros((1, 256, 512), device=dev)
     pt = torch.zeros(256, device=dev)
