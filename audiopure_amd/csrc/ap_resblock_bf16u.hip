@@ -120,13 +120,10 @@ int launch_init_conv_u(ap_ctx *ctx, const float *x, const float *pt0, void *u, i
 }
 
 // NOH: the net's last layer -- GEMM1, the gate and the g image only.
-// NCHR (tools builds instantiate values below 8; timing only, results wrong by construction): GEMM1 runs the first NCHR of its 8
-// chunks -- what the launch would cost with that share of the dilated conv's matrix work gone and NOTHING added for it, i.e. an
-// upper bound on what a minimal-filtering form of GEMM1 (2/3 of the products) could gain (tools/ab_bf16u_flops.py).
 // SAVEF (the differentiable purifier's forward pass, ap_resblock_fwd_u_save): + the gate's derivative factors, an fp16 pair per (channel,
 // sample) in the accumulators' order [clip][tile][wave][column tile][q][lane] x 16 bytes -- the image ap_resblock_bwd_bf16_saved reads
 // (ap_resblock_bf16p.hip, SAVEF: same geometry); u' and the g image are bit-identical to the launch without it.
-template <bool NOH, int NCHR = 8, bool SAVEF = false>
+template <bool NOH, bool SAVEF = false>
 __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
     const void *__restrict__ uin, void *__restrict__ uout, const float *__restrict__ ptn,       // images in / out, the NEXT layer's part_t
     const void *__restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,        // bf16 weight images (one slab)
@@ -343,13 +340,13 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
       }
     };
 #pragma unroll 1
-    for (int ch = 0; ch < NCHR - 2; ch++) {
+    for (int ch = 0; ch < NCH - 2; ch++) {
       chunk(lds + (ch & 1) * XBYTES + rdoff, ch, lds + ((ch + 1) & 1) * XBYTES, I0{});
       __syncthreads();
     }
-    chunk(lds + ((NCHR - 2) & 1) * XBYTES + rdoff, NCHR - 2, lds + ((NCHR - 1) & 1) * XBYTES, I1{});
+    chunk(lds + ((NCH - 2) & 1) * XBYTES + rdoff, NCH - 2, lds + ((NCH - 1) & 1) * XBYTES, I1{});
     __syncthreads();
-    chunk(lds + ((NCHR - 1) & 1) * XBYTES + rdoff, NCHR - 1, nullptr, I2{});
+    chunk(lds + ((NCH - 1) & 1) * XBYTES + rdoff, NCH - 1, nullptr, I2{});
 
     // ================================================ gate ==========================================================
     // GEMM2's first requests and the residual's rows of u go out ahead of the gate.  The residual: this wave's res rows are chunk
@@ -550,10 +547,6 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
   }
 }
 
-#ifdef AP_TOOLS
-extern int g_dbg_bf16;
-#endif
-
 bool resblock_bf16u_serves(const ap_ctx *ctx, int L) {
   return ctx->cfg.precision == AP_PREC_BF16_STORE && ctx->C == 256 && ctx->S == 256 && L >= 1 &&
          (size_t)L * 512 < ((size_t)1 << 31);
@@ -583,25 +576,13 @@ int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *
   const unsigned b1_off = (unsigned)((ctx->b1 - blo + (size_t)layer * 2 * C) * 4);
   const unsigned b2_off = (unsigned)((ctx->b2 - blo + (size_t)layer * (C + S)) * 4);
   const unsigned bbytes = (unsigned)((bhi - blo + (size_t)ctx->NL * 2 * C) * 4);
-#ifdef AP_TOOLS
-  if (uout && (g_dbg_bf16 & 0x30000000)) {                       // timing only: GEMM1 over 6 / 5 of its 8 chunks
-    if ((g_dbg_bf16 & 0x30000000) == 0x10000000)
-      resblock_bf16u_kernel<false, 6><<<(unsigned)grid, 512, 0, st>>>(uin, uout, pt_next, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d,
-                                                                      ntiles, nblk, gout);
-    else
-      resblock_bf16u_kernel<false, 5><<<(unsigned)grid, 512, 0, st>>>(uin, uout, pt_next, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off, L, d,
-                                                                      ntiles, nblk, gout);
-    AP_HIP(hipGetLastError());
-    return 0;
-  }
-#endif
   if (fout) {                                                    // the differentiable purifier's forward: + the gate's derivative factors
     if ((size_t)ntiles * 131072 >= ((size_t)1 << 31)) { set_error("AP_PREC_BF16_STORE: clip too long for the gate-factor image"); return -22; }
     if (uout)
-      resblock_bf16u_kernel<false, 8, true><<<(unsigned)grid, 512, 0, st>>>(uin, uout, pt_next, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off,
+      resblock_bf16u_kernel<false, true><<<(unsigned)grid, 512, 0, st>>>(uin, uout, pt_next, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off,
                                                                             L, d, ntiles, nblk, gout, fout);
     else
-      resblock_bf16u_kernel<true, 8, true><<<(unsigned)grid, 512, 0, st>>>(uin, nullptr, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off,
+      resblock_bf16u_kernel<true, true><<<(unsigned)grid, 512, 0, st>>>(uin, nullptr, nullptr, wlo, wbytes, w1_off, w2_off, blo, bbytes, b1_off, b2_off,
                                                                            L, d, ntiles, nblk, gout, fout);
     AP_HIP(hipGetLastError());
     return 0;

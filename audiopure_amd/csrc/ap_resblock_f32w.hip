@@ -97,16 +97,12 @@ int launch_pack_f32w(ap_ctx *ctx, hipStream_t st) {
 // each 32 x 32 accumulator tile leaves as 1 row x 4 samples per lane -- 16-byte stores, the residual's h patch and the running skip
 // rows as 16-byte loads (skip += as a read-modify-write: one workgroup owns a tile within a launch, launches are stream-ordered,
 // so the sum is as deterministic as the float atomics of the 4-byte form).  A CU's store path moves a 4-byte-per-lane store
-// stream at a fraction of its 16-byte rate: the 4-byte epilogue cost 6.5 % of the launch (tools/ablate_f32w.py).
-template <bool NOH, int ABL = 0, bool SAVE = false, bool Q16 = false>
+// stream at a fraction of its 16-byte rate: the 4-byte epilogue cost 6.5 % of the launch (tools/ab_f32w.py).
+template <bool NOH, bool SAVE = false, bool Q16 = false>
 __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     const float *__restrict__ hin, const float *__restrict__ pt, float *__restrict__ hout, float *__restrict__ skip,
     const float *__restrict__ w1w, const float *__restrict__ b1, const float *__restrict__ w2w,
     const float *__restrict__ b2, int L, int logd, int accumulate, int ntiles, int nblk, float *__restrict__ aout) {
-  constexpr int ablate = ABL;
-  // (tools builds only instantiate ABL != 0; timing only, results wrong by construction) ablate: 1 gate math, 2 epilogue stores, 4 residual loads,
-  // 8 X loads of the chunk loop, 16 GEMM1 weight loads, 32 staging transform + LDS writes, 64 per-chunk barrier, 128 GEMM1 MFMAs,
-  // 256 GEMM2 MFMAs, 512 GEMM2 weight loads
   constexpr int C = WC_;
   __shared__ __attribute__((aligned(16))) float lds[Q16 ? LDS_FLOATS_Q16_ : LDS_FLOATS_];
 
@@ -230,12 +226,6 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 
 #pragma unroll 1
   for (int tile = t_first; tile < t_end; tile += t_step) {
-    if ((ablate & 2048) && tile != t_first) {                    // (A/B variant of the tools build: no cross-tile prefetch)
-      set_tile(tile);
-#pragma unroll
-      for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
-      issue_x(0);
-    }
     f32x16 acc[4][4];                                            // [product][row tile]; the dilated conv's bias rides on m2 (in both outputs)
 #pragma unroll
     for (int rt = 0; rt < 4; rt++) {
@@ -259,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 #pragma unroll 1
     for (int ch = 0; ch < NCH_; ch++) {
       const float *xb = xfrag + (ch & 1) * XBUF_;
-      if (!(ablate & 8)) issue_x(ch + 1 < NCH_ ? ch + 1 : ch);   // (no branches in this loop: the last chunk re-requests itself, unused)
+      issue_x(ch + 1 < NCH_ ? ch + 1 : ch);   // (no branches in this loop: the last chunk re-requests itself, unused)
       f32x4 bq[2];
       bq[0] = *reinterpret_cast<const f32x4 *>(xb);
       __builtin_amdgcn_sched_barrier(0);
@@ -271,13 +261,13 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
           if (u + 1 < 16) bq[(u + 1) & 1] = *reinterpret_cast<const f32x4 *>(xb + ((u + 1) & 3) * XCOMP_ + ((u + 1) >> 2) * 8);
           // the next chunk's FiLM add / padding / differences / LDS writes ride in the MFMA gaps of unit 12 (the X loads were
           // requested twelve units = 12 k cycles ago)
-          if (u == 12 && !(ablate & 32)) store_x(lds + ((ch + 1) & 1) * XBUF_);
+          if (u == 12) store_x(lds + ((ch + 1) & 1) * XBUF_);
 #pragma unroll
           for (int e = 0; e < 4; e++)
 #pragma unroll
             for (int rt = 0; rt < 4; rt++)
-              if (!(ablate & 128)) acc[comp][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[comp][rt][e], bq[u & 1][e], acc[comp][rt], 0, 0, 0);
-          if (u == 12 && !(ablate & 32)) {
+              acc[comp][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[comp][rt][e], bq[u & 1][e], acc[comp][rt], 0, 0, 0);
+          if (u == 12) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -287,11 +277,11 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
           }
           __builtin_amdgcn_sched_barrier(0);
           // the same product's unit of the next k-group takes over this unit's registers
-          if (!(ablate & 16)) load_a1(a[comp], (unsigned)((16 * ch + u + 4) & (16 * NCH_ - 1)));   // (the last k-group wraps to the image's first units, unused)
+          load_a1(a[comp], (unsigned)((16 * ch + u + 4) & (16 * NCH_ - 1)));   // (the last k-group wraps to the image's first units, unused)
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (!(ablate & 64)) __syncthreads();
+      __syncthreads();
     }
 
     // sample of GEMM2 column (ct, j)
@@ -329,8 +319,8 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
             const float sa = (acc[0][2 * p + 1][r] + acc[1][2 * p + 1][r]) + acc[2][2 * p + 1][r];
             const float tb = (acc[1][2 * p][r] - acc[2][2 * p][r]) + acc[3][2 * p][r];
             const float sb = (acc[1][2 * p + 1][r] - acc[2][2 * p + 1][r]) + acc[3][2 * p + 1][r];
-            v0[e] = (ablate & 1) ? ta + sa : gate(ta, sa);
-            v1[e] = (ablate & 1) ? tb + sb : gate(tb, sb);
+            v0[e] = gate(ta, sa);
+            v1[e] = gate(tb, sb);
             if constexpr (SAVE) {                                // channel 64 wave + 32 p + rowoff(r, hh), samples of this lane's pair
               const unsigned so = ((unsigned)(64 * wave + 32 * p + 4 * hh) * (unsigned)L) * 4u;
               const int ro = ((r & 3) + 8 * (r >> 2)) * L * 4;
@@ -393,15 +383,10 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
           for (int ct = 0; ct < 2; ct++)
 #pragma unroll
             for (int p = 0; p < 4; p++)
-              hq[rt][ct][p] = (ablate & 4) ? f32x4{0.f, 0.f, 0.f, 0.f}
-                                           : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, eo4[ct], (32 * rt + 8 * p) * L * 4, 2));
+              hq[rt][ct][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, eo4[ct], (32 * rt + 8 * p) * L * 4, 2));
       }
     }
-    if (!Q16 && (ablate & 4)) {
-#pragma unroll
-      for (int i = 0; i < 64; i++) (&hres[0][0][0])[i] = 0.f;
-    }
-    if (!Q16 && !NOH && !(ablate & 4)) {
+    if (!Q16 && !NOH) {
 #pragma unroll
       for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -430,9 +415,9 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
             for (int rt = NOH ? 2 : 0; rt < 4; rt++)
 #pragma unroll
               for (int ct = 0; ct < 2; ct++)
-                if (!(ablate & 256)) acc2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[k & 1][rt][e], bq2[ct][e], acc2[rt][ct], 0, 0, 0);
+                acc2[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[k & 1][rt][e], bq2[ct][e], acc2[rt][ct], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
-          if (!(ablate & 512)) load_a2(a2[k & 1], (unsigned)((kg + 2) & (C / 8 - 1)));
+          load_a2(a2[k & 1], (unsigned)((kg + 2) & (C / 8 - 1)));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -468,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 #pragma unroll
         for (int p = 0; p < 4; p++) out4(p, *reinterpret_cast<const f32x4 *>(patch + (rowq + 8 * p) * PS_ + 4 * cq));
       };
-      if (!(ablate & 2) || accumulate == 0x12345) {
+      {
         if (!NOH) {
 #pragma unroll
           for (int rt = 0; rt < 2; rt++)
@@ -480,14 +465,14 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
               });
         }
       }
-      if (!(ablate & 2048)) {
+      {
         set_tile(tile + t_step < t_end ? tile + t_step : tile);  // (the last tile re-requests itself, unused)
 #pragma unroll
         for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
         issue_x(0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (!(ablate & 2) || accumulate == 0x12345) {
+      {
 #pragma unroll
         for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -503,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
     // order, so requested after them their wait would include the 64 float atomics (thousands of cycles each to retire with every
     // CU issuing them); requested before, it includes at most the plain h' stores (the counter holds 63: the wait for these loads
     // lets the youngest 63 operations -- the atomics -- stay outstanding)
-    if (!(ablate & 2048)) {
+    {
       set_tile(tile + t_step < t_end ? tile + t_step : tile);    // (the last tile re-requests itself, unused)
 #pragma unroll
       for (int u = 0; u < 4; u++) load_a1(a[u], (unsigned)u);
@@ -513,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 
     // ---- epilogue (WaveNet.py:97, :133): buffer stores / memory-side float atomics -- one VGPR offset per 32 x 32 tile, the row
     // stride in SGPR offsets, columns past the clip's end dropped by the range check (no address arithmetic, no branches)
-    if (!(ablate & 2) || accumulate == 0x12345) {               // (ablated: kept behind a condition that is never true, so nothing upstream is dead code)
+    {
       typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
       const float RS = 0.707106781186547524f;   // float(math.sqrt(0.5))
 #pragma unroll
@@ -548,7 +533,6 @@ __global__ __launch_bounds__(256, 1) void resblock_f32w_kernel(
 }
 
 #ifdef AP_TOOLS
-static int g_ablate_f32w = 0;
 static int g_no_q16 = 0;                                        // ap_debug_f32w_q16(0): the 4-byte epilogue for every clip length (A/B)
 #else
 static constexpr int g_no_q16 = 0;
@@ -580,43 +564,15 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
   const bool q16 = (L & 3) == 0 && !g_no_q16;
   if (aout) {
     if (!hout) { set_error("resblock (save): needs an h' buffer"); return -22; }
-    if (q16) resblock_f32w_kernel<false, 0, true, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
-    else resblock_f32w_kernel<false, 0, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
+    if (q16) resblock_f32w_kernel<false, true, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
+    else resblock_f32w_kernel<false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, aout);
     AP_HIP(hipGetLastError());
     return 0;
   }
-#define AP_F32W(ABL)                                                                                                           \
-  do {                                                                                                                         \
-    if (hout && q16) resblock_f32w_kernel<false, ABL, false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
-    else if (hout) resblock_f32w_kernel<false, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
-    else if (q16) resblock_f32w_kernel<true, ABL, false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr); \
-    else resblock_f32w_kernel<true, ABL><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);      \
-  } while (0)
-#ifdef AP_TOOLS
-  switch (g_ablate_f32w) {                                       // each mask its own clean instantiation (tools/ablate_f32w.py)
-    case 0: AP_F32W(0); break;
-    case 1: AP_F32W(1); break;
-    case 2: AP_F32W(2); break;
-    case 4: AP_F32W(4); break;
-    case 6: AP_F32W(6); break;
-    case 8: AP_F32W(8); break;
-    case 16: AP_F32W(16); break;
-    case 32: AP_F32W(32); break;
-    case 40: AP_F32W(40); break;
-    case 64: AP_F32W(64); break;
-    case 512: AP_F32W(512); break;
-    case 528: AP_F32W(528); break;
-    case 128: AP_F32W(128); break;
-    case 256: AP_F32W(256); break;
-    case 384: AP_F32W(384); break;
-    case 639: AP_F32W(639); break;
-    case 2048: AP_F32W(2048); break;
-    default: set_error("ap_debug_ablate_f32w: mask %d is not instantiated", g_ablate_f32w); return -22;
-  }
-#else
-  AP_F32W(0);
-#endif
-#undef AP_F32W
+  if (hout && q16) resblock_f32w_kernel<false, false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);
+  else if (hout) resblock_f32w_kernel<false><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);
+  else if (q16) resblock_f32w_kernel<true, false, true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);
+  else resblock_f32w_kernel<true><<<grid, 256, 0, st>>>(hin, pt, hout, skip, w1w, b1, w2w, b2, L, logd, accumulate, ntiles, (int)nblk, nullptr);
   AP_HIP(hipGetLastError());
   return 0;
 }
@@ -626,10 +582,6 @@ int launch_resblock_f32w(ap_ctx *ctx, int layer, const float *hin, const float *
 #ifdef AP_TOOLS
 extern "C" int ap_debug_f32w_q16(int on) {
   ap::g_no_q16 = on ? 0 : 1;
-  return 0;
-}
-extern "C" int ap_debug_ablate_f32w(int mask) {
-  ap::g_ablate_f32w = mask;
   return 0;
 }
 #endif

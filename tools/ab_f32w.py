@@ -1,5 +1,6 @@
-"""Same-process A/B of variants of the F(2,3) fp32 block (tools build; variant masks >= 1024 keep the results right).
-   python tools/ab_f32w.py [B] [mask ...]"""
+"""Same-process A/B of the F(2,3) fp32 block's two epilogue forms (tools build): 16-byte stores through LDS patches (clip lengths
+that are multiples of four) against the 4-byte form every other length takes.
+   python tools/ab_f32w.py [B]"""
 import sys
 
 import _toolslib  # noqa: F401
@@ -13,7 +14,6 @@ from audiopure_amd.diffusion_models.DiffWave_Unconditional.WaveNet import WaveNe
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    masks = [int(a) for a in sys.argv[2:]] or [0, 2048]
     dev = torch.device("cuda:0")
     cfg = synth.mini_wavenet_config(256, 12, 12)
     net = WaveNet_Speech_Commands(**cfg)
@@ -21,7 +21,6 @@ def main():
     net = net.to(dev)
     eng = net.engine()
     lib = eng.lib
-    lib.ap_debug_ablate_f32w.argtypes = [C.c_int]
     L = 16000
     hd = torch.rand(B, 256, L, device=dev) * 3 - 1.5
     hout = torch.empty_like(hd)
@@ -29,8 +28,7 @@ def main():
     pt = torch.rand(256, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def t(layer, mask, n=6):
-        lib.ap_debug_ablate_f32w(mask)
+    def t(layer, n=6):
         for _ in range(2):
             N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
         e0.record()
@@ -38,17 +36,16 @@ def main():
             N.check(lib.ap_resblock_fwd(eng.ctx, layer, N.ptr(hd), N.ptr(pt), N.ptr(hout), N.ptr(sk), 1, B, L, N.stream()))
         e1.record()
         torch.cuda.synchronize()
-        lib.ap_debug_ablate_f32w(0)
         return e0.elapsed_time(e1) / n
 
     lib.ap_debug_f32w_q16.argtypes = [C.c_int]
     for rep in range(2):
         for layer in (0, 5, 11):
-            row = [t(layer, m) for m in masks]
+            t16 = t(layer)
             lib.ap_debug_f32w_q16(0)
-            t4 = t(layer, 0)
+            t4 = t(layer)
             lib.ap_debug_f32w_q16(1)
-            print(f"layer {layer:2d}  " + "  ".join(f"mask {m}: {ms:7.3f} ms" for m, ms in zip(masks, row)) + f"   4-byte epilogue: {t4:7.3f} ms", flush=True)
+            print(f"layer {layer:2d}  16-byte epilogue: {t16:7.3f} ms   4-byte epilogue: {t4:7.3f} ms", flush=True)
 
 
 if __name__ == "__main__":

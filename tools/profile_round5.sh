@@ -17,7 +17,7 @@ cp "$repo/$out"/stats/*kernel_stats.csv "$repo/$out/kernel_stats.csv" 2>/dev/nul
 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 "$repo/bench.py" --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-other-modes --no-other-configs > "$repo/$out/bench_torchrun_n1.json" 2> "$repo/$out/bench_torchrun_n1.err"
 bash "$repo/tools/pmc_kernel.sh" "$out/pmc_f32w" resblock_f32w -- "$repo/tools/run_resblock.py" 512 f32 2 > "$repo/$out/pmc_f32w.log" 2>&1
 bash "$repo/tools/pmc_kernel.sh" "$out/pmc_f32d" resblock_f32_kernel -- "$repo/tools/run_resblock.py" 512 f32d 2 > "$repo/$out/pmc_f32d.log" 2>&1
-( cd "$repo/tools" && timeout 600 python3 ablate_f32w.py 256 2>&1 | grep -v amdgpu.ids > "$repo/$out/f32w_ablation.txt"; timeout 300 python3 ab_f32w.py 256 0 2048 2>&1 | grep -v amdgpu.ids > "$repo/$out/f32w_ab.txt";
+( cd "$repo/tools" && timeout 300 python3 ab_f32w.py 256 2>&1 | grep -v amdgpu.ids > "$repo/$out/f32w_ab.txt";
   timeout 300 python3 ab_conv_w3.py 256 2>&1 | grep -v amdgpu.ids > "$repo/$out/conv_w3_ab.txt" )
 timeout 600 python3 "$repo/tools/conv_by_shape.py" 256 2>&1 | grep -v amdgpu.ids > "$repo/$out/cfg4_conv_by_shape.txt"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/cfg4_stats" -o r -- python3 "$repo/tools/run_cfg4_step.py" 256 3 > "$repo/$out/cfg4_step.log" 2>&1

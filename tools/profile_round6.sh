@@ -20,9 +20,9 @@ timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mas
 bash "$repo/tools/pmc_kernel.sh" "$out/pmc_f32w" resblock_f32w -- "$repo/tools/run_resblock.py" 512 f32 2 > "$repo/$out/pmc_f32w.log" 2>&1
 B=512 bash "$repo/tools/profile_bf16_modes.sh" "$out/bf16_modes" > "$repo/$out/bf16_modes.log" 2>&1
 ( cd "$repo"; GRAFT_REPO_ROOT="$repo" bash tools/pmc_f32s_forms.sh 2>&1 | grep -v amdgpu.ids > "$repo/$out/f32s_forms.txt"; timeout 300 python3 tools/time_f32s_forms.py 512 5 8 2>&1 | grep -v amdgpu.ids >> "$repo/$out/f32s_forms.txt" )
-( cd "$repo/tools" && timeout 300 python3 ab_bf16u_flops.py 512 5 20 2>&1 | grep -v amdgpu.ids > "$repo/$out/bf16u_flops_ab.txt" )
 timeout 300 python3 "$repo/tools/bench_whitebox.py" 10 5 f32 2>&1 | grep -v amdgpu.ids > "$repo/$out/whitebox.txt"
 timeout 300 python3 "$repo/tools/bench_whitebox.py" 10 5 bf16 2>&1 | grep -v amdgpu.ids > "$repo/$out/whitebox_bf16.txt"
+timeout 300 python3 "$repo/tools/bench_whitebox.py" 10 5 bf16s 2>&1 | grep -v amdgpu.ids > "$repo/$out/whitebox_bf16s.txt"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/wbb_stats" -o r -- python3 "$repo/tools/bench_whitebox.py" 10 5 bf16 > "$repo/$out/wbb_stats.log" 2>&1
 cp "$repo/$out"/wbb_stats/*kernel_stats.csv "$repo/$out/whitebox_bf16_kernel_stats.csv" 2>/dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$repo/$out/wb_stats" -o r -- python3 "$repo/tools/bench_whitebox.py" 10 5 f32 > "$repo/$out/wb_stats.log" 2>&1

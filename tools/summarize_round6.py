@@ -33,8 +33,9 @@ def cp(name, dst, json_line=False):
 
 cp("bench.json", "r6_bench.json", True)
 cp("bench_torchrun_n1.json", "r6_bench_torchrun_n1.json", True)
-for a, b in (("kernel_stats.csv", "r6_kernel_stats.csv"), ("f32s_forms.txt", "r6_f32s_forms_rerun.txt"), ("bf16u_flops_ab.txt", "r6_bf16s_fewer_products_upper_bound_rerun.txt"),
-             ("whitebox.txt", "r6_whitebox_gradient_step.txt"), ("whitebox_bf16.txt", "r6_whitebox_bf16_gradient_step.txt"),
+for a, b in (("kernel_stats.csv", "r6_kernel_stats.csv"), ("f32s_forms.txt", "r6_f32s_forms_rerun.txt"), ("bf16u_flops_ab.txt", "r6_bf16s_fewer_products_upper_bound_rerun.txt"),   # (runs up to tree f081186 only: the hook was removed afterwards)
+            
+             ("whitebox.txt", "r6_whitebox_gradient_step.txt"), ("whitebox_bf16.txt", "r6_whitebox_bf16_gradient_step.txt"), ("whitebox_bf16s.txt", "r6_whitebox_bf16s_gradient_step.txt"),
              ("whitebox_kernel_stats.csv", "r6_whitebox_kernel_stats.csv"), ("whitebox_bf16_kernel_stats.csv", "r6_whitebox_bf16_kernel_stats.csv"),
              ("pmc_bwdb_gate/summary.json", "r6_whitebox_bf16_gate_kernel_pmc.json"), ("pmc_bwdb_conv/summary.json", "r6_whitebox_bf16_conv_kernel_pmc.json"),
              ("cfg4_conv_by_shape.txt", "r6_cfg4_conv_by_shape.txt"), ("cfg4_kernel_stats.csv", "r6_cfg4_kernel_stats.csv"),
