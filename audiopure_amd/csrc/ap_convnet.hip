@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
 // rows of an MFMA tile empty (the generic kernel ran it at 0.8 TFLOP/s).  One thread per output pixel instead, the whole
 // filter in LDS ([k][m], k = ci kh kw + ky kw + kx as packed for the generic kernel), an fp32 fma chain in k order; reads are
 // coalesced along W and the taps re-read L1 / L2.  Same contract as conv2d_f32_kernel (groups = 1).
-template <int MO>
+// K3 (3 x 3 taps, dilation 1 -- the UNet's layer): the nine taps' offsets and validity once per thread, then nine unconditional
+// loads per channel (clamped address, value selected) with four channels unrolled = 36 loads in flight; with run-time tap loops
+// every load was waited for before the next was issued (0.31 ms per launch at B = 256; same fma order, same result).
+template <int MO, bool K3 = false>
 __global__ __launch_bounds__(256) void conv2d_few_kernel(ConvArgs a) {
   extern __shared__ float wsm[];
   const int KK = a.kh * a.kw, Kg = a.Cin * KK, HoWo = a.Ho * a.Wo, N = a.B * HoWo, HW = a.H * a.W;
@@ -129,6 +132,32 @@ __global__ __launch_bounds__(256) void conv2d_few_kernel(ConvArgs a) {
   float acc[MO];
 #pragma unroll
   for (int m = 0; m < MO; m++) acc[m] = 0.f;
+  if constexpr (K3) {
+    int off[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+      ok[t] = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      off[t] = ok[t] ? iy * a.W + ix : 0;
+    }
+    float v[2][9];                                             // channel ci + 1 is requested before channel ci's fma chain runs
+#pragma unroll
+    for (int t = 0; t < 9; t++) v[0][t] = xb[off[t]];
+#pragma unroll 2
+    for (int ci = 0; ci < a.Cin; ci++) {
+      const float *xn = xb + (size_t)(ci + 1 < a.Cin ? ci + 1 : ci) * HW;
+      const float *wk = wsm + (size_t)ci * 9 * MO;
+#pragma unroll
+      for (int t = 0; t < 9; t++) v[(ci + 1) & 1][t] = xn[off[t]];
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const float vt = ok[t] ? v[ci & 1][t] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MO; m++) acc[m] = fmaf(wk[t * MO + m], vt, acc[m]);
+      }
+    }
+  } else
 #pragma unroll 4                                                // (four channels' taps in flight: the loop is load-latency bound)
   for (int ci = 0; ci < a.Cin; ci++) {
     const float *xc = xb + (size_t)ci * HW;
@@ -1342,7 +1371,12 @@ int conv2d_fwd_impl(const float *x, const float *wT, const float *bias, const fl
     const unsigned grid = (unsigned)((N + 255) / 256);
     const size_t sh = (size_t)Cin * kh * kw * Cout * sizeof(float);
     *cls = 5;
-    switch (Cout) {
+    const bool k3 = kh == 3 && kw == 3 && a.dil_h == 1 && a.dil_w == 1;
+    switch (k3 ? -Cout : Cout) {
+      case -1: conv2d_few_kernel<1, true><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
+      case -2: conv2d_few_kernel<2, true><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
+      case -3: conv2d_few_kernel<3, true><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
+      case -4: conv2d_few_kernel<4, true><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
       case 1: conv2d_few_kernel<1><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
       case 2: conv2d_few_kernel<2><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
       case 3: conv2d_few_kernel<3><<<grid, 256, sh, (hipStream_t)stream>>>(a); break;
