@@ -39,12 +39,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#ifndef AP_UPOL
-#define AP_UPOL 2
-#endif
-#ifndef AP_GPOL
-#define AP_GPOL 2
-#endif
 constexpr int PT_ = 128;                 // time tile
 constexpr int KC_ = 32;                  // channels per chunk -> 96 K rows = 6 k-steps of 16
 constexpr int XS_ = 3 * KC_ + 8;         // bf16 per column row of the X image (208 B: conflict-free ds_read_b128 B fragments)
@@ -525,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
             o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16x2));
           }
           // (offset step in the VGPR, soffset = 0: a >8-byte buffer store with an SGPR soffset reads its data late: ap_resblock_bf16p.hip)
-          __builtin_amdgcn_raw_buffer_store_b128(o, uors, ro[ct] + (unsigned)(32 * s), 0, AP_UPOL);   // nt: written once, read by the next launch
+          __builtin_amdgcn_raw_buffer_store_b128(o, uors, ro[ct] + (unsigned)(32 * s), 0, 2);   // nt: written once, read by the next launch
         }
       }
     }
@@ -545,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void resblock_bf16u_kernel(
         const u32x4 v = *reinterpret_cast<const u32x4 *>(src + 16 * i * (GS_ * 2));
         const int t = t0 + colw + 16 * i;
         const unsigned off = t < L ? (unsigned)t * 512u + (unsigned)q * 16u : 0x80000000u;   // outside the clip: dropped
-        __builtin_amdgcn_raw_buffer_store_b128(v, grs, off, 0, AP_GPOL);
+        __builtin_amdgcn_raw_buffer_store_b128(v, grs, off, 0, 2);
       }
     }
     b_cur = b_nxt;

@@ -99,7 +99,22 @@ class NativeEngine:
         self.skip_group = min(self.SKIP_GROUP, cfg["num_res_layers"])
         self._ds_ok = (precision in (N.AP_PREC_BF16, N.AP_PREC_BF16_STORE) and cfg["res_channels"] == 256 and cfg["skip_channels"] == 256)
 
+    BIG_WS = 4 << 30
+
+    def _drop_ws(self):
+        """Let go of the workspace.  One of tens of GB (B = 512 in a bf16 mode: 150-165 GB) goes straight back to the driver: parked in
+        torch's caching allocator, the next small allocation would be carved out of it and pin the whole segment, and a later
+        workspace of a different size would not fit beside it."""
+        big = self.ws is not None and self.ws.numel() >= self.BIG_WS
+        self.ws = None
+        if big:
+            torch.cuda.empty_cache()
+
     def __del__(self):
+        try:
+            self._drop_ws()
+        except Exception:
+            pass
         try:
             if getattr(self, "ctx", None):
                 self.lib.ap_ctx_destroy(self.ctx)
@@ -134,8 +149,12 @@ class NativeEngine:
         self._sync_group()
         need = self.lib.ap_workspace_bytes(self.ctx, B, L)
         if self.ws is None or self.ws.numel() < need or self.ws.device != device:
-            self.ws = None
-            self.ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._drop_ws()
+            try:
+                self.ws = torch.empty(need, dtype=torch.uint8, device=device)
+            except torch.OutOfMemoryError:
+                torch.cuda.empty_cache()                     # (free blocks of other sizes the cache still holds)
+                self.ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self.ws
 
     def clips_that_fit(self, L: int, device) -> int:

@@ -49,7 +49,7 @@ class EpsGrad:
     def _prepare(self):
         net = self.net
         eng = net.engine()
-        key = (id(eng), eng.loaded_key)
+        key = (eng.serial, eng.loaded_key, net._precision)   # (serial, not id(): a precision switch builds a new engine, possibly at the old one's address)
         if self._key == key:
             return eng
         lib, dev = eng.lib, next(net.parameters()).device

@@ -421,6 +421,24 @@ def test_bf16_store_purifier_is_differentiable_end_to_end(dev, dh):
     assert rc == -22 and b"AP_PREC_BF16_STORE" in eng.lib.ap_last_error()
 
 
+def test_gradients_survive_precision_switches_on_one_net(dev):
+    """bench.py's white-box leg walks one net through f32 -> bf16 -> bf16s: every switch builds a new engine (possibly at the old one's
+    address), and the gradient object must notice -- ap_ctx_prepare_backward once per engine, never a stale 'already prepared'."""
+    cfg = synth.mini_wavenet_config(256, 6, 12)
+    net, _ = _net(cfg, dev, seed=6, mode="f32")
+    x0 = torch.from_numpy(synth.waveforms(2, 1200, seed=3)).to(dev)
+    got = {}
+    for mode in ("f32", "bf16", "bf16s", "bf16", "f32", "bf16s"):
+        net.set_precision(mode)
+        xg = x0.clone().requires_grad_(True)
+        net.eps(xg, 2.0).sum().backward()
+        assert torch.isfinite(xg.grad).all()
+        if mode in got:
+            assert torch.equal(got[mode], xg.grad)                # the same engine state again: the same bits
+        got[mode] = xg.grad.clone()
+    assert _cos(got["bf16s"], got["f32"]) > 0.99 and _cos(got["bf16"], got["f32"]) > 0.99
+
+
 def test_bf16_store_chain_is_hip_graph_capturable(dh, dev):
     """The mode's launches (37 per evaluation + the skip GEMM) capture into a HIP graph; a replay equals the eager call bit for bit."""
     from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
