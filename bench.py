@@ -172,7 +172,7 @@ PREC_NAME = {"f32": "fp32 (v_mfma_f32_32x32x2_f32; dilated conv in F(2,3) minima
                      "dilated conv; held to the fp32 tolerances and to 2 x the fp32 kernel's error on adversarial operands)"}
 
 
-PMC_FILES = {"f32": ["r5_f32w_pmc_traffic.json"], "f32d": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3_f32s_pmc_traffic.json", "r2_f32s_pmc_traffic.json"],
+PMC_FILES = {"f32": ["r6_f32w_pmc_traffic.json", "r5_f32w_pmc_traffic.json"], "f32d": ["r3_pmc_traffic.json", "r2_pmc_traffic.json"], "f32s": ["r3_f32s_pmc_traffic.json", "r2_f32s_pmc_traffic.json"],
              "bf16": ["r6_bf16_pmc_traffic.json", "r4_bf16_pmc_traffic.json"], "bf16s": ["r6_bf16s_pmc_traffic.json"]}
 
 
