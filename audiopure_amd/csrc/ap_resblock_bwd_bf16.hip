@@ -13,6 +13,8 @@
 // (sample, tap) operand is a contiguous 256-byte run of the dy image.  Built for res = skip = 256 channels.
 // Where the time goes at the white-box shape (B = 10: K1 0.30 ms, K2 0.19 ms per layer; MFMA pipes 26 % / 32 % busy, tools/time_bwd_bf16.py,
 // docs/HISTORY.md H): every tile re-reads its weight fragments (1 MB / 0.8 MB) through the CU's vector-memory path beside its activations.
+// Round 6: K1 has a second form that reads gate factors the forward kept instead of recomputing them (resblock_bwd_gate_fac_bf16_kernel,
+// 0.13-0.14 ms per layer; the default of the differentiable purifier, docs/HISTORY.md I.5).
 #include <type_traits>
 
 #include "ap_common.h"
