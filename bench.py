@@ -747,7 +747,8 @@ def main():
         from audiopure_amd.diffusion_models.diffwave_sde import RevDiffWave
         dh_ = calc_diffusion_hyperparams(**synth.DIFFUSION_CONFIG)
         ref_rate = {"f32": (world * B * args.steps / elapsed) if args.precision == "f32" else others.get("f32", {}).get("value"),
-                    "bf16": (world * B * args.steps / elapsed) if args.precision == "bf16" else others.get("bf16", {}).get("value")}
+                    "bf16": (world * B * args.steps / elapsed) if args.precision == "bf16" else others.get("bf16", {}).get("value"),
+                    "bf16s": (world * B * args.steps / elapsed) if args.precision == "bf16s" else others.get("bf16s", {}).get("value")}
 
         def timed(fn, reps=2):
             fn()
@@ -762,9 +763,9 @@ def main():
                                  f"{B}-clip batch in the same arithmetic mode; then one_shot_denoise + M5 at B=10 (certification), one "
                                  "white-box gradient step (RevDiffWave t=5 + M5 + nll_loss, forward + backward w.r.t. the audio) at B=10, and "
                                  "BASELINE configs[0]'s B=2, n=1 on the GPU", "ddpm_n5": {}}
-        for prec in ("f32", "bf16"):
+        for prec in ("f32", "bf16", "bf16s"):
             rows = {}
-            for b in (1, 2, 10, 50) + ((500,) if prec == "bf16" else ()):
+            for b in (1, 2, 10, 50) + ((500,) if prec != "f32" else ()):
                 if b > B:
                     continue
                 st = 2
