@@ -205,6 +205,8 @@ int launch_resblock_bf16p(ap_ctx *ctx, int layer, const float *hin, const float 
 // AP_PREC_BF16_STORE (ap_resblock_bf16u.hip): the residual stream as bf16 images of u = h + part_t, [clip][C / 32][L][32]
 bool resblock_bf16u_serves(const ap_ctx *ctx, int L);
 int launch_init_conv_u(ap_ctx *ctx, const float *x, const float *pt0, void *u, int B, int L, hipStream_t st);
+bool resblock_bf16us_serves(const ap_ctx *ctx, int B, int L);     // AP_PREC_BF16_STORE, at most one 128-sample tile per CU: 64-sample tiles (ap_resblock_bf16us.hip)
+int launch_resblock_bf16us(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st);
 int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *pt_next, void *uout, void *gout, int B, int L, hipStream_t st,
                           void *fout = nullptr);                  // uout null: the net's last layer; fout: + the gate's derivative factors
 int launch_skipgemm_bf16(ap_ctx *ctx, int layer0, int nl, const void *gimg, float *skip, int accumulate, int B, int L, hipStream_t st);

@@ -559,6 +559,8 @@ int launch_resblock_bf16u(ap_ctx *ctx, int layer, const void *uin, const float *
     set_error("AP_PREC_BF16_STORE: built for res = skip = 256 channels, clips shorter than 2^22 samples (got %d / %d, L = %d)", ctx->C, ctx->S, L);
     return -22;
   }
+  // launches of at most one tile per CU (one- and two-clip calls): 64-sample tiles on twice as many workgroups, bit-identical results
+  if (!fout && resblock_bf16us_serves(ctx, B, L)) return launch_resblock_bf16us(ctx, layer, uin, pt_next, uout, gout, B, L, st);
   const int C = ctx->C, S = ctx->S;
   const int d = 1 << (layer % ctx->cfg.dilation_cycle);
   const int n_cu = device_cu_count();

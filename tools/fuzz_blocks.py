@@ -76,23 +76,41 @@ for i in range(cases):
     from_img = lambda im: im.float().permute(0, 1, 3, 2)[:, :, PERM, :].reshape(B, 256, L)
     ub = h.to(torch.bfloat16).float()
     uin, zero = to_img(ub), torch.zeros(256, device=dev)
-    prev = None
-    for rep in range(2):
-        G, n = 1024, h.numel()
-        ubuf = torch.full((n + 2 * G,), 7.25, device=dev, dtype=torch.bfloat16)
-        gb = torch.full((n + 2 * G,), 7.25, device=dev, dtype=torch.bfloat16)
-        uo, gi = ubuf[G:G + n].view(B, 8, L, 32), gb[G:G + n]
-        N.check(eu.lib.ap_resblock_fwd_u(eu.ctx, layer, uin.data_ptr(), N.ptr(pt), uo.data_ptr(), gi.data_ptr(), B, L, N.stream()))
-        for nm, buf in (("u'", ubuf), ("g image", gb)):
-            if not (bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all())):
-                print(f"OUT-OF-BOUNDS WRITE {nm} bf16s B={B} L={L} layer={layer}"); bad += 1
-        if prev is not None and not (torch.equal(prev[0].view(torch.int16), uo.view(torch.int16)) and torch.equal(prev[1].view(torch.int16), gi.view(torch.int16))):
-            print(f"NONDETERMINISTIC bf16s B={B} L={L} layer={layer}"); bad += 1
-        prev = (uo.clone(), gi.clone())
-    g2 = torch.empty_like(prev[1])
-    N.check(eu.lib.ap_resblock_fwd_u(eu.ctx, layer, uin.data_ptr(), None, None, g2.data_ptr(), B, L, N.stream()))
-    if not torch.equal(g2.view(torch.int16), prev[1].view(torch.int16)):
-        print(f"LAST-LAYER FORM: OTHER g IMAGE bf16s B={B} L={L} layer={layer}"); bad += 1
+    # both kernels of the mode (tools library: ap_debug_no_bf16us 1 = the persistent 128-sample-tile kernel, 2 = the 64-sample-tile kernel
+    # of one- and two-clip launches): each twice inside guard bands, the last-layer form, and the two against each other bit for bit
+    try:
+        toggle = eu.lib.ap_debug_no_bf16us
+        flags = (1, 2)
+    except AttributeError:
+        toggle, flags = None, (0,)
+    per_kernel = {}
+    for flag in flags:
+        if toggle is not None:
+            toggle(flag)
+        prev = None
+        for rep in range(2):
+            G, n = 1024, h.numel()
+            ubuf = torch.full((n + 2 * G,), 7.25, device=dev, dtype=torch.bfloat16)
+            gb = torch.full((n + 2 * G,), 7.25, device=dev, dtype=torch.bfloat16)
+            uo, gi = ubuf[G:G + n].view(B, 8, L, 32), gb[G:G + n]
+            N.check(eu.lib.ap_resblock_fwd_u(eu.ctx, layer, uin.data_ptr(), N.ptr(pt), uo.data_ptr(), gi.data_ptr(), B, L, N.stream()))
+            for nm, buf in (("u'", ubuf), ("g image", gb)):
+                if not (bool((buf[:G] == 7.25).all()) and bool((buf[G + n:] == 7.25).all())):
+                    print(f"OUT-OF-BOUNDS WRITE {nm} bf16s kernel {flag} B={B} L={L} layer={layer}"); bad += 1
+            if prev is not None and not (torch.equal(prev[0].view(torch.int16), uo.view(torch.int16)) and torch.equal(prev[1].view(torch.int16), gi.view(torch.int16))):
+                print(f"NONDETERMINISTIC bf16s kernel {flag} B={B} L={L} layer={layer}"); bad += 1
+            prev = (uo.clone(), gi.clone())
+        g2 = torch.empty_like(prev[1])
+        N.check(eu.lib.ap_resblock_fwd_u(eu.ctx, layer, uin.data_ptr(), None, None, g2.data_ptr(), B, L, N.stream()))
+        if not torch.equal(g2.view(torch.int16), prev[1].view(torch.int16)):
+            print(f"LAST-LAYER FORM: OTHER g IMAGE bf16s kernel {flag} B={B} L={L} layer={layer}"); bad += 1
+        per_kernel[flag] = prev
+    if toggle is not None:
+        toggle(0)
+        if not (torch.equal(per_kernel[1][0].view(torch.int16), per_kernel[2][0].view(torch.int16)) and
+                torch.equal(per_kernel[1][1].view(torch.int16), per_kernel[2][1].view(torch.int16))):
+            d_u = float((per_kernel[1][0].float() - per_kernel[2][0].float()).abs().max())
+            print(f"SMALL-TILE KERNEL != PERSISTENT KERNEL bf16s B={B} L={L} layer={layer}: max |du'| {d_u:.3e}"); bad += 1
     hb_, gb_ = torch.empty_like(h), torch.empty_like(prev[1])
     N.check(eb.lib.ap_resblock_fwd_gate(eb.ctx, layer, N.ptr(ub), N.ptr(zero), N.ptr(hb_), gb_.data_ptr(), B, L, N.stream()))
     ref_u = (hb_ + pt.view(1, -1, 1)).to(torch.bfloat16).float()
