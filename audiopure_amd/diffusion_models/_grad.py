@@ -255,10 +255,8 @@ class EpsGrad:
         self._conv(lib, skip, self.wf1, self.bf1, None, r, B, S_, L, S_, 1, 0, 1)
         dr = torch.empty_like(r)
         N.check(lib.ap_relu_outer_bwd(N.ptr(r), N.ptr(self.wf2), N.ptr(d_eps), N.ptr(dr), B, S_, L, st), "ap_relu_outer_bwd")
-        z = torch.empty((B, C_ + S_, L), device=dev)             # [RS dh' ; dskip], dskip is the same for every block
         dskip = r                                                 # reuse
         self._conv(lib, dr, self.wf1_t, None, None, dskip, B, S_, L, S_, 1, 0, 1)
-        N.check(lib.ap_copy_channels(N.ptr(dskip), N.ptr(z), B, S_, L, S_, 0, C_ + S_, C_, st), "ap_copy_channels")
         dh = torch.zeros((B, C_, L), device=dev)                  # the last block's h' output is not used (WaveNet.py:133)
         if pre is not None and self.net._precision == N.AP_PREC_F32 and lib.ap_resblock_bwd_available(eng.ctx, B, L):
             # the shipped shape in fp32: two fused launches per layer (ap_resblock_bwd.hip) -- the gate's derivative as the epilogue of
@@ -297,6 +295,8 @@ class EpsGrad:
             dx = torch.empty((B, 1, L), device=dev)
             N.check(lib.ap_init_conv_bwd(N.ptr(hs[0]), N.ptr(self.w0), N.ptr(dh), N.ptr(dx), B, C_, L, st), "ap_init_conv_bwd")
             return dx
+        z = torch.empty((B, C_ + S_, L), device=dev)             # [RS dh' ; dskip], dskip is the same for every block (the composed path only)
+        N.check(lib.ap_copy_channels(N.ptr(dskip), N.ptr(z), B, S_, L, S_, 0, C_ + S_, C_, st), "ap_copy_channels")
         t1 = torch.empty_like(dh)
         dg = torch.empty_like(dh)
         u = torch.empty_like(dh) if pre is None else None
