@@ -439,6 +439,29 @@ def test_gradients_survive_precision_switches_on_one_net(dev):
     assert _cos(got["bf16s"], got["f32"]) > 0.99 and _cos(got["bf16"], got["f32"]) > 0.99
 
 
+@pytest.mark.parametrize("mode", ["bf16s", "bf16"])
+def test_bf16_modes_denoise_helpers_against_the_reference_vectors(golden, dh, dev, mode):
+    """The single-evaluation helpers the certification and the attacks call (diffwave_ddpm.py:166-226: one_shot_denoise at t* = 1 and 25,
+    two_shot_denoise at 25, compute_coefficients) in the two bf16 modes against the REFERENCE's own fp32 outputs on the shipped net:
+    x0-hat within 3e-3 of max (one evaluation's bf16 error scaled by sqrt(1 - abar) / sqrt(abar) <= 0.15; measured 1.1e-4 at t* = 1,
+    1.6-1.7e-3 at 25), the two-shot form within 6e-3 (1.7-1.8e-3), eps itself within 3e-2 (1.25e-2 / 1.42e-2; the oracle's emulation of the same arithmetic: 1.5e-2, profiles/r6_bf16_f23_cpu_gate.txt); what the modes are held to bit-tightly is their own oracle emulation (the tests above)."""
+    from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
+    net, _ = _net(dict(synth.FULL_WAVENET_CONFIG), dev, mode=mode)
+    x0 = torch.from_numpy(synth.waveforms(2, 16000, seed=1234)).to(dev)
+    got = {}
+    for t in (1, 25):
+        dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=t)
+        got[f"one_shot_t{t}"] = rel_err(dw.one_shot_denoise(x0).cpu().numpy(), golden[f"full/one_shot_t{t}"])
+    dw = DiffWave(model=net, diffusion_hyperparams=dh, reverse_timestep=25)
+    got["two_shot_t25"] = rel_err(dw.two_shot_denoise(x0).cpu().numpy(), golden["full/two_shot_t25"])
+    eps, _, _ = dw.compute_coefficients(x0, 4)
+    got["eps_t4"] = rel_err(eps.cpu().numpy(), golden["full/eps_t4"])
+    print(mode, {k: f"{v:.2e}" for k, v in got.items()})
+    assert got["one_shot_t1"] < 3e-3 and got["one_shot_t25"] < 3e-3, got
+    assert got["two_shot_t25"] < 6e-3, got
+    assert got["eps_t4"] < 3e-2, got
+
+
 def test_bf16_store_chain_is_hip_graph_capturable(dh, dev):
     """The mode's launches (37 per evaluation + the skip GEMM) capture into a HIP graph; a replay equals the eager call bit for bit."""
     from audiopure_amd.diffusion_models.diffwave_ddpm import DiffWave
