@@ -700,6 +700,7 @@ def main():
 
     elapsed, k_ms, launches = run_mode(args.precision, args.steps, args.warmup)
     head_digest = scores_digest(run_mode.last_scores)
+    head_scores = run_mode.last_scores.detach().float().cpu()   # the same clips and the same Philox draws run in every mode below
     head_power = run_mode.power
     head_roof = roofline(args.precision, k_ms, launches)        # (now: run_mode.chunk / .split describe the run just made)
     ranks = rank_evidence(use_dist, run_mode.local_elapsed, device_descriptor(torch, local), "nccl")
@@ -719,6 +720,12 @@ def main():
             others[prec] = {"arithmetic": PREC_NAME[prec], "value": round(B * st / e2, 3), "unit": "utterances/s",
                             "steps": st, "ms_per_step": round(e2 * 1e3 / st, 3), "roofline": roofline(prec, k2, l2),
                             "power": run_mode.power}
+            sc = run_mode.last_scores.detach().float().cpu()
+            # the reduced-precision paths' agreement with the headline arithmetic on the same clips and noise, reported
+            others[prec]["scores_vs_headline"] = {
+                "clips": int(sc.shape[0]), "classes_in_headline_decisions": int(head_scores.argmax(1).unique().numel()),
+                "argmax_agreement": round(float((sc.argmax(1) == head_scores.argmax(1)).float().mean()), 5),
+                "max_abs_dlogp": float(f"{float((sc - head_scores).abs().max()):.3e}")}
 
     other_configs = {}
     if world == 1 and not args.no_other_configs:
