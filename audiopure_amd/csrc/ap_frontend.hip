@@ -189,7 +189,9 @@ __device__ __forceinline__ void m5_stage_bwd(const float *dout, const float *pou
   }
 }
 
-__global__ __launch_bounds__(256) void m5_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dlogp,
+// (1 024 threads: every loop below strides by blockDim.x and each output is one thread's own fma chain, so the thread count changes
+// the time -- the stages are latency-bound gathers -- and not a bit of the result)
+__global__ __launch_bounds__(1024) void m5_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dlogp,
                                                      float *__restrict__ dx, const float *__restrict__ w1,
                                                      const float *__restrict__ b1, const float *__restrict__ w2,
                                                      const float *__restrict__ b2, const float *__restrict__ w3,
@@ -262,7 +264,7 @@ int launch_m5_bwd(ap_m5 *m, const float *x, const float *dlogp, float *dx, int B
     AP_HIP(hipFuncSetAttribute((const void *)m5_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  m5_bwd_kernel<<<B, 256, smem, st>>>(x, dlogp, dx, m->w[0], m->b[0], m->w[1], m->b[1], m->w[2], m->b[2], m->w[3], m->b[3],
+  m5_bwd_kernel<<<B, 1024, smem, st>>>(x, dlogp, dx, m->w[0], m->b[0], m->w[1], m->b[1], m->w[2], m->b[2], m->w[3], m->b[3],
                                      m->fcw, m->fcb, L, nc, m->k1, m->stride, m->n_output, Q1, Q2, Q3, Q4);
   AP_HIP(hipGetLastError());
   return 0;
