@@ -1,5 +1,5 @@
-"""Times one eps evaluation (B clips, AP_PREC_BF16_STORE) per library given on the command line, each in its own process, round-robin.
-   python tools/time_bf16s_variants.py B rounds lib1.so lib2.so ...     (child: --child)"""
+"""Times one eps evaluation (B clips; AP_PREC_BF16_STORE, or the mode in AP_TIME_MODE) per library given on the command line, each in its own
+process, round-robin.   python tools/time_bf16s_variants.py B rounds lib1.so lib2.so ...     (child: --child)"""
 import os, subprocess, sys, time
 here = os.path.dirname(os.path.abspath(__file__))
 if sys.argv[1] == "--child":
@@ -12,7 +12,7 @@ if sys.argv[1] == "--child":
     cfg = dict(synth.FULL_WAVENET_CONFIG)
     net = WaveNet_Speech_Commands(**cfg)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.wavenet_state_dict(cfg, 0).items()})
-    net = net.to(dev).set_precision("bf16s")
+    net = net.to(dev).set_precision(os.environ.get("AP_TIME_MODE", "bf16s"))
     x = torch.from_numpy(synth.waveforms(B, 16000, seed=6)).to(dev).reshape(B, 1, 16000)
     with torch.no_grad():
         for _ in range(2):
